@@ -1,0 +1,362 @@
+// Exact kNN-2 (L2 over integer descriptors) + Lowe ratio test for gfx950.
+//
+// Replaces Stitcher.get_matches / filter_matches (reference stitcher.py:106-127, matcher built at
+// stitcher.py:85 = cv2.BFMatcher() => NORM_L2) and the loop body of get_collections
+// (stitcher.py:285-296).
+//
+// Arithmetic.  With a' = a-128, b' = b-128 (int8):  ||a-b||^2 = na' + nb' - 2 a'.b'   (exact int32).
+// For a fixed query the ranking over train rows j needs only  val_j = 2 a'.b'_j - nb'_j + BIAS  (>0),
+// larger = nearer.  One int8 MFMA chain gives a'.b' for a 32(train) x 32(query) tile; the train rows
+// land in the 16 accumulator registers of a lane and the query on the lane, so each lane owns ONE
+// running top-2 per query column block and updates it with 3 VALU ops per distance:
+//       key = (acc << 9) + cbase_j|code      (v_lshl_add_u32)   key = val<<8 | code
+//       m2  = med3(m1, m2, key)              (v_med3_u32)
+//       m1  = max(m1, key)                   (v_max_u32)
+// `code` (8 bit) orders the <=256 train rows a lane sees inside a 512-row segment so that equal
+// distances resolve to the LOWEST train index, as cv2's insertion rule does; every 512 rows the
+// (m1,m2) pair is folded into a (val, j) state with strict comparisons (earlier rows win ties).
+// sqrtf is taken for the two survivors only; it is injective on the integer range admitted by
+// ISX_L2_EXACT_LIMIT, so integer ranking == cv2's float ranking (checked by the caller).
+#include "isx_common.h"
+#include <float.h>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define ISX_BIAS 6291456 /* 3 << 21 : keeps val = 2dot - nb' + BIAS in [32768, 2^23] */
+
+// ------------------------------------------------------------------------------------------------
+// Descriptor preparation: (u8 | integer-valued f32) -> int8 (v-128), norms, key bases.
+// One 16-byte output unit per thread; UPR = DP/16 threads cooperate on a row.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int UPR>
+__global__ void __launch_bounds__(256) desc_prep_kernel(const T *__restrict__ src, int64_t rows, int d,
+                                                        int8_t *__restrict__ desc,
+                                                        uint32_t *__restrict__ cbase,
+                                                        int32_t *__restrict__ nrm,
+                                                        int32_t *__restrict__ stats) {
+    constexpr int DP = UPR * 16;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t / UPR;
+    const int unit = (int)(t % UPR);
+    int sq_off = 0, sq_raw = 0, bad = 0;
+    union {
+        v4i v;
+        int8_t b[16];
+    } out;
+    out.v = v4i{0, 0, 0, 0};
+    if (row < rows) {
+        const T *p = src + row * (int64_t)d;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int k = unit * 16 + e;
+            int v = 128; // padding: offset value 0
+            if (k < d) {
+                if constexpr (sizeof(T) == 1) {
+                    v = (int)p[k];
+                } else {
+                    const float f = (float)p[k];
+                    const int iv = (int)f;
+                    if (!((float)iv == f) || iv < 0 || iv > 255) {
+                        bad = 1;
+                        v = iv < 0 ? 0 : (iv > 255 ? 255 : iv);
+                        if (!(f == f)) v = 0;
+                    } else {
+                        v = iv;
+                    }
+                }
+                sq_raw += v * v;
+            }
+            const int o = v - 128;
+            sq_off += o * o;
+            out.b[e] = (int8_t)o;
+        }
+        *(v4i *)(desc + row * (int64_t)DP + unit * 16) = out.v;
+    }
+    // reduce over the UPR lanes of the row (UPR is a power of two <= 8, rows never straddle a wave)
+#pragma unroll
+    for (int m = 1; m < UPR; m <<= 1) {
+        sq_off += __shfl_xor(sq_off, m);
+        sq_raw += __shfl_xor(sq_raw, m);
+    }
+    if (row < rows && unit == 0) {
+        nrm[row] = sq_off;
+        cbase[row] = (uint32_t)(ISX_BIAS - sq_off) << 8;
+    }
+    // stats: wave-level reduce then one atomic per wave
+    int mx = row < rows ? sq_raw : 0;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int o = __shfl_xor(mx, m);
+        mx = o > mx ? o : mx;
+    }
+    const unsigned long long anybad = __ballot(bad);
+    if ((threadIdx.x & 63) == 0) {
+        if (mx > 0) atomicMax(&stats[1], mx);
+        if (anybad) atomicOr(&stats[0], 1);
+    }
+}
+
+extern "C" int isx_desc_pad(int d) {
+    if (d <= 0) return isx_fail(ISX_E_ARG, "descriptor width must be positive (got %d)", d);
+    if (d <= 32) return 32;
+    if (d <= 64) return 64;
+    if (d <= 128) return 128;
+    return isx_fail(ISX_E_UNSUPPORTED, "descriptor width %d > 128 bytes is not supported by the integer L2 path", d);
+}
+
+template <typename T>
+static int prep_launch(const void *src, int64_t rows, int d, int dp, int8_t *desc, uint32_t *cbase,
+                       int32_t *nrm, int32_t *stats, hipStream_t st) {
+    const int upr = dp / 16;
+    const int64_t threads = rows * upr;
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (upr == 2)
+        hipLaunchKernelGGL((desc_prep_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T *)src, rows, d, desc, cbase, nrm, stats);
+    else if (upr == 4)
+        hipLaunchKernelGGL((desc_prep_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const T *)src, rows, d, desc, cbase, nrm, stats);
+    else
+        hipLaunchKernelGGL((desc_prep_kernel<T, 8>), dim3(grid), dim3(256), 0, st, (const T *)src, rows, d, desc, cbase, nrm, stats);
+    return isx_launch_status("desc_prep_kernel");
+}
+
+extern "C" int isx_desc_prep(const void *src_dev, int src_dtype, int64_t rows, int d, int8_t *desc_dev,
+                             uint32_t *cbase_dev, int32_t *nrm_dev, int32_t *stats_dev, void *stream) {
+    const int dp = isx_desc_pad(d);
+    if (dp < 0) return dp;
+    ISX_REQUIRE(rows >= 0 && rows < ((int64_t)1 << 31) / 8, "rows=%lld out of range", (long long)rows);
+    ISX_REQUIRE(src_dtype == ISX_U8 || src_dtype == ISX_F32, "src_dtype must be ISX_U8 or ISX_F32");
+    if (rows == 0) return ISX_OK;
+    ISX_REQUIRE(src_dev && desc_dev && cbase_dev && nrm_dev && stats_dev, "null device pointer");
+    ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == ISX_U8) return prep_launch<uint8_t>(src_dev, rows, d, dp, desc_dev, cbase_dev, nrm_dev, stats_dev, st);
+    return prep_launch<float>(src_dev, rows, d, dp, desc_dev, cbase_dev, nrm_dev, stats_dev, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kNN-2 + ratio kernel.  Block = 4 waves x 64 queries; train rows stream through LDS in 128-row
+// chunks (double buffered, register staged).  blockIdx -> (item, query block) is XCD aware: blocks
+// that share blockIdx%8 share an XCD/L2, so item e is served entirely by XCD e%8 and the caller
+// orders items so that consecutive items on one XCD share their train image.
+// ------------------------------------------------------------------------------------------------
+struct Cand {
+    unsigned v; // val (0 = absent)
+    int j;      // train row local to the item (-1 = absent)
+};
+
+__device__ __forceinline__ bool cand_better(const Cand a, const Cand b) {
+    return a.v > b.v || (a.v == b.v && (unsigned)a.j < (unsigned)b.j);
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256)
+knn2_l2_kernel(const int8_t *__restrict__ desc, const uint32_t *__restrict__ cbase,
+               const int32_t *__restrict__ nrm, const isx_knn_item *__restrict__ items, int n_items,
+               int nqb, double ratio, int32_t *__restrict__ idx_out, float *__restrict__ dist_out,
+               const int64_t *__restrict__ out_start, int32_t *__restrict__ count_out) {
+    constexpr int DP = 32 * KS;
+    constexpr int SLOTS = 2 * KS;
+    constexpr int SH = (KS == 4) ? 1 : (KS == 2) ? 2 : 3;
+    constexpr int CHUNK = 128;
+    constexpr int BUF = CHUNK * DP + CHUNK * 4;
+    __shared__ __align__(16) unsigned char smem[2 * BUF];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int k = id >> 3;
+    const int qb = k % nqb;
+    const int item_i = (k / nqb) * 8 + xcd;
+    if (item_i >= n_items) return;
+    const isx_knn_item it = items[item_i];
+    if (qb * 256 >= it.nq) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const int q0 = qb * 256 + wave * 64;
+    const int nt = it.nt;
+
+    // query fragments (MFMA B operand): lane holds query column `col`, k bytes [32ks+16h, +16)
+    v4i qf[2][KS];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        const int qi = q0 + cb * 32 + col;
+        const v4i *p = (const v4i *)(desc + (int64_t)(it.q_start + (qi < it.nq ? qi : 0)) * DP);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qf[cb][ks] = (qi < it.nq) ? p[2 * ks + h] : v4i{0, 0, 0, 0};
+    }
+    const bool cb_live[2] = {q0 < it.nq, q0 + 32 < it.nq};
+
+    unsigned m1[2] = {0u, 0u}, m2[2] = {0u, 0u};
+    Cand g1[2], g2[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        g1[cb] = Cand{0u, -1};
+        g2[cb] = Cand{0u, -1};
+    }
+
+    const int n_chunks = (nt + CHUNK - 1) / CHUNK;
+    v4i st[KS];
+    unsigned st_cb = 0;
+
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < KS; i++) {
+            const int u = tid + 256 * i;
+            const int row = u / SLOTS, slot = u % SLOTS;
+            const int jl = c * CHUNK + row;
+            st[i] = (jl < nt) ? *(const v4i *)(desc + (int64_t)(it.t_start + jl) * DP + slot * 16)
+                              : v4i{0, 0, 0, 0};
+        }
+        if (tid < CHUNK) {
+            const int jl = c * CHUNK + tid;
+            const int tt = (c & 3) * 4 + (tid >> 5);
+            const int rho = tid & 31;
+            const int code = 255 - 16 * tt - ((rho & 3) + 4 * (rho >> 3));
+            st_cb = (jl < nt) ? (cbase[it.t_start + jl] + (unsigned)code) : 0u;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        unsigned char *base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < KS; i++) {
+            const int u = tid + 256 * i;
+            const int row = u / SLOTS, slot = u % SLOTS;
+            *(v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4)) = st[i];
+        }
+        if (tid < CHUNK) *(unsigned *)(base + CHUNK * DP + tid * 4) = st_cb;
+    };
+
+    if (n_chunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks) load_chunk(c + 1);
+        const unsigned char *base = smem + buf * BUF;
+#pragma unroll
+        for (int tl = 0; tl < 4; tl++) {
+            if (c * CHUNK + tl * 32 < nt) {
+                const int row = tl * 32 + col;
+                v4i a[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const int slot = 2 * ks + h;
+                    a[ks] = *(const v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4));
+                }
+                v4i cv[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    cv[g] = *(const v4i *)(base + CHUNK * DP + (tl * 32 + 8 * g + 4 * h) * 4);
+#pragma unroll
+                for (int cb = 0; cb < 2; cb++) {
+                    if (cb_live[cb]) {
+                        v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                        for (int ks = 0; ks < KS; ks++)
+                            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], qf[cb][ks], acc, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const unsigned key = ((unsigned)acc[r] << 9) + (unsigned)cv[r >> 2][r & 3];
+                            const unsigned lo = m1[cb] < key ? m1[cb] : key;
+                            const unsigned hi = m1[cb] < key ? key : m1[cb];
+                            const unsigned t2 = hi < m2[cb] ? hi : m2[cb];
+                            m2[cb] = lo > t2 ? lo : t2; // med3(m1, m2, key)
+                            m1[cb] = hi;
+                        }
+                    }
+                }
+            }
+        }
+        if (c + 1 < n_chunks) store_chunk(buf ^ 1);
+        __syncthreads();
+
+        if ((c & 3) == 3 || c == n_chunks - 1) {
+            const int seg = c >> 2;
+#pragma unroll
+            for (int cb = 0; cb < 2; cb++) {
+#pragma unroll
+                for (int w = 0; w < 2; w++) {
+                    const unsigned key = w == 0 ? m1[cb] : m2[cb];
+                    const unsigned v = key >> 8;
+                    const int pos = 255 - (int)(key & 255u);
+                    const int r = pos & 15;
+                    const int j = seg * 512 + (pos >> 4) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (v > g1[cb].v) {
+                        g2[cb] = g1[cb];
+                        g1[cb] = Cand{v, j};
+                    } else if (v > g2[cb].v) {
+                        g2[cb] = Cand{v, j};
+                    }
+                }
+                m1[cb] = 0u;
+                m2[cb] = 0u;
+            }
+        }
+    }
+
+    // merge the two lane halves (same query, disjoint train rows), then lanes 0..31 finish the row
+    int good_cnt = 0;
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        Cand o1, o2;
+        o1.v = __shfl_xor(g1[cb].v, 32);
+        o1.j = __shfl_xor(g1[cb].j, 32);
+        o2.v = __shfl_xor(g2[cb].v, 32);
+        o2.j = __shfl_xor(g2[cb].j, 32);
+        Cand top, sec;
+        if (cand_better(g1[cb], o1)) {
+            top = g1[cb];
+            sec = cand_better(g2[cb], o1) ? g2[cb] : o1;
+        } else {
+            top = o1;
+            sec = cand_better(g1[cb], o2) ? g1[cb] : o2;
+        }
+        const int qi = q0 + cb * 32 + col;
+        bool good = false;
+        if (h == 0 && qi < it.nq) {
+            const int na = nrm[it.q_start + qi];
+            const bool has0 = top.v != 0u, has1 = sec.v != 0u;
+            const float d0 = has0 ? sqrtf((float)(na + ISX_BIAS - (int)top.v)) : FLT_MAX;
+            const float d1 = has1 ? sqrtf((float)(na + ISX_BIAS - (int)sec.v)) : FLT_MAX;
+            good = has0 && (!has1 || (double)d0 < ratio * (double)d1);
+            if (idx_out) {
+                const int64_t o = (out_start[item_i] + qi) * 2;
+                idx_out[o] = has0 ? top.j : -1;
+                idx_out[o + 1] = has1 ? sec.j : -1;
+                dist_out[o] = d0;
+                dist_out[o + 1] = d1;
+            }
+        }
+        good_cnt += __popcll(__ballot(good));
+    }
+    if (count_out && lane == 0 && good_cnt) atomicAdd(&count_out[item_i], good_cnt);
+}
+
+extern "C" int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_dev, const int32_t *nrm_dev,
+                                 int d_pad, const isx_knn_item *items_dev, int n_items, int max_nq,
+                                 double ratio, int32_t *idx_out_dev, float *dist_out_dev,
+                                 const int64_t *out_start_dev, int32_t *count_out_dev, void *stream) {
+    ISX_REQUIRE(d_pad == 32 || d_pad == 64 || d_pad == 128, "d_pad must be 32, 64 or 128 (got %d)", d_pad);
+    ISX_REQUIRE(n_items >= 0 && max_nq >= 0, "negative size");
+    ISX_REQUIRE((idx_out_dev == nullptr) == (dist_out_dev == nullptr), "idx_out and dist_out must be given together");
+    ISX_REQUIRE(idx_out_dev == nullptr || out_start_dev != nullptr, "out_start_dev is required with idx/dist outputs");
+    if (n_items == 0 || max_nq == 0) return ISX_OK;
+    ISX_REQUIRE(desc_dev && cbase_dev && nrm_dev && items_dev, "null device pointer");
+    ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
+    const int nqb = (max_nq + 255) / 256;
+    const int64_t blocks = (int64_t)((n_items + 7) / 8) * 8 * nqb;
+    ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)blocks), block(256);
+    if (d_pad == 128)
+        hipLaunchKernelGGL((knn2_l2_kernel<4>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
+    else if (d_pad == 64)
+        hipLaunchKernelGGL((knn2_l2_kernel<2>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
+    else
+        hipLaunchKernelGGL((knn2_l2_kernel<1>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
+    return isx_launch_status("knn2_l2_kernel");
+}

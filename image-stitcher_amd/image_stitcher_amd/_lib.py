@@ -1,0 +1,55 @@
+"""ctypes binding of libisx_hip.so (include/isx.h).  No CPU fallback: if the library is missing the
+import of any compute op fails loudly."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libisx_hip.so")
+
+U8, F32 = 0, 1
+NORM_L2, NORM_HAMMING = 0, 1
+MODEL_AFFINE_PARTIAL, MODEL_HOMOGRAPHY = 0, 1
+BLEND_ALPHA, BLEND_GRADIENT = 0, 1
+L2_EXACT_LIMIT = 4197200
+
+c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+
+# name -> (restype, argtypes); every symbol include/isx.h declares
+SIGNATURES = {
+    "isx_version": (c_int, []),
+    "isx_last_error": (ctypes.c_char_p, []),
+    "isx_device_count": (c_int, []),
+    "isx_desc_pad": (c_int, [c_int]),
+    "isx_desc_prep": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "isx_knn2_l2_items": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+class IsxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IsxError(
+                f"{LIB_PATH} is missing: build it with `python image-stitcher_amd/build.py` "
+                "(there is no CPU fallback for the stitching core)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status < 0:
+        raise IsxError(f"isx error {status}: {lib().isx_last_error().decode()}")
+    return status

@@ -1,0 +1,188 @@
+"""Tensor-level wrappers over the C ABI (include/isx.h).  PyTorch is used only to own device memory
+and streams; every kernel is in libisx_hip.so.  There is no CPU fallback."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import IsxError, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require_cuda(t, name):
+    if not t.is_cuda:
+        raise IsxError(f"{name} must live on a HIP device (got {t.device}); the stitching core has no CPU path")
+
+
+class PreparedDescriptors:
+    """Descriptors of one or more images, resident in HBM in the layout the matcher consumes
+    (int8 value-128 rows padded to 32/64/128 bytes, per-row key bases and norms)."""
+
+    def __init__(self, desc, cbase, nrm, starts, counts, d, d_pad, max_norm2):
+        self.desc, self.cbase, self.nrm = desc, cbase, nrm
+        self.starts = np.asarray(starts, np.int64)  # first row of every image
+        self.counts = np.asarray(counts, np.int64)  # rows of every image
+        self.d, self.d_pad, self.max_norm2 = d, d_pad, max_norm2
+
+    @property
+    def n_images(self):
+        return len(self.counts)
+
+    @property
+    def device(self):
+        return self.desc.device
+
+
+def prepare_descriptors(des_list, device=None, check_range=True):
+    """des_list: list of (n_i, d) uint8 / float32 arrays or tensors (one per image; None or empty
+    allowed).  Float descriptors must be integer valued in [0,255] (cv2 SIFT's are).  Returns
+    PreparedDescriptors on `device`."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    tens, counts = [], []
+    d = None
+    dtype = None
+    for a in des_list:
+        if a is None:
+            counts.append(0)
+            continue
+        t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+        if t.ndim != 2:
+            raise IsxError("descriptors must be 2-D (n, d)")
+        if t.shape[0] == 0:
+            counts.append(0)
+            continue
+        if d is None:
+            d, dtype = t.shape[1], t.dtype
+        elif t.shape[1] != d or t.dtype != dtype:
+            raise IsxError("all descriptor arrays must share dtype and width")
+        tens.append(t)
+        counts.append(t.shape[0])
+    if d is None:
+        raise IsxError("no descriptors given")
+    if dtype not in (torch.uint8, torch.float32):
+        raise IsxError(f"descriptor dtype must be uint8 or float32 (got {dtype})")
+    src = torch.cat([t.to(device, non_blocking=True) for t in tens], 0).contiguous()
+    starts = np.concatenate([[0], np.cumsum(counts)])[:-1]
+    return prepare_descriptor_tensor(src, starts, counts, check_range)
+
+
+def prepare_descriptor_tensor(src, starts, counts, check_range=True):
+    """src: (R, d) uint8/float32 device tensor holding all images back to back."""
+    _require_cuda(src, "src")
+    L = _lib.lib()
+    rows, d = src.shape
+    d_pad = check(L.isx_desc_pad(d))
+    dev = src.device
+    with torch.cuda.device(dev):
+        desc = torch.empty((rows, d_pad), dtype=torch.int8, device=dev)
+        cbase = torch.empty((rows,), dtype=torch.int32, device=dev)
+        nrm = torch.empty((rows,), dtype=torch.int32, device=dev)
+        stats = torch.zeros((2,), dtype=torch.int32, device=dev)
+        check(L.isx_desc_prep(_ptr(src), _lib.U8 if src.dtype == torch.uint8 else _lib.F32, rows, d,
+                              _ptr(desc), _ptr(cbase), _ptr(nrm), _ptr(stats), _stream()))
+        max_norm2 = None
+        if check_range:
+            s = stats.cpu().numpy()
+            if s[0] & 1:
+                raise IsxError("float descriptors are not integer valued in [0,255]: "
+                               "use the float32 matcher (knn2_f32) instead of the exact integer path")
+            max_norm2 = int(s[1])
+            if 2 * max_norm2 >= _lib.L2_EXACT_LIMIT:
+                raise IsxError(f"descriptor norms too large for the exact integer path "
+                               f"(2*{max_norm2} >= {_lib.L2_EXACT_LIMIT})")
+    return PreparedDescriptors(desc, cbase, nrm, starts, counts, d, d_pad, max_norm2)
+
+
+def order_items_for_xcd(items):
+    """Reorder directed work items (n,4 int32: q_start,nq,t_start,nt) so that the 8 XCD-private L2s
+    each walk a contiguous run of train images: the kernel serves item e on XCD e%8.  Returns
+    (items_interleaved (m,4), perm (m,) original index or -1 for padding)."""
+    items = np.asarray(items, np.int32).reshape(-1, 4)
+    n = len(items)
+    if n == 0:
+        return items, np.zeros((0,), np.int64)
+    order = np.lexsort((items[:, 0], items[:, 2]))  # by train image, then query
+    per = (n + 7) // 8
+    perm = np.full((per, 8), -1, np.int64)
+    for x in range(8):
+        chunk = order[x * per:(x + 1) * per]
+        perm[:len(chunk), x] = chunk
+    perm = perm.reshape(-1)
+    out = np.zeros((len(perm), 4), np.int32)
+    valid = perm >= 0
+    out[valid] = items[perm[valid]]
+    return out, perm
+
+
+def knn2_l2_items(P, items, ratio, want_matches=False, xcd_order=True):
+    """Run the fused kNN-2 + ratio kernel over directed work items.
+
+    items: (n,4) int32 rows (q_start, nq, t_start, nt) into P's row space.
+    Returns counts (n,) int32 device tensor [len(good_matches) per item] and, if want_matches,
+    (idx, dist, out_starts): idx/dist are (sum nq, 2) device tensors, out_starts (n,) numpy int64.
+    """
+    L = _lib.lib()
+    items = np.ascontiguousarray(np.asarray(items, np.int32).reshape(-1, 4))
+    n = len(items)
+    dev = P.device
+    with torch.cuda.device(dev):
+        if n == 0:
+            z = torch.zeros((0,), dtype=torch.int32, device=dev)
+            return (z, None) if want_matches else z
+        if xcd_order and n > 8:
+            run_items, perm = order_items_for_xcd(items)
+        else:
+            run_items, perm = items, np.arange(n)
+        m = len(run_items)
+        max_nq = int(run_items[:, 1].max())
+        items_dev = torch.from_numpy(run_items).to(dev, non_blocking=True)
+        counts = torch.zeros((m,), dtype=torch.int32, device=dev)
+        idx = dist = out_dev = None
+        out_starts = None
+        if want_matches:
+            out_run = np.concatenate([[0], np.cumsum(run_items[:, 1].astype(np.int64))])
+            total = int(out_run[-1])
+            idx = torch.empty((total, 2), dtype=torch.int32, device=dev)
+            dist = torch.empty((total, 2), dtype=torch.float32, device=dev)
+            out_dev = torch.from_numpy(out_run[:-1].copy()).to(dev, non_blocking=True)
+        check(L.isx_knn2_l2_items(_ptr(P.desc), _ptr(P.cbase), _ptr(P.nrm), P.d_pad, _ptr(items_dev), m,
+                                  max_nq, float(ratio), _ptr(idx), _ptr(dist), _ptr(out_dev),
+                                  _ptr(counts), _stream()))
+        if xcd_order and n > 8:
+            valid = perm >= 0
+            inv_np = np.empty((n,), np.int64)
+            inv_np[perm[valid]] = np.nonzero(valid)[0]
+            counts_o = counts[torch.from_numpy(inv_np).to(dev)]
+            if want_matches:
+                out_starts = out_run[:-1][inv_np]
+        else:
+            counts_o = counts
+            if want_matches:
+                out_starts = out_run[:-1]
+        if want_matches:
+            return counts_o, (idx, dist, out_starts)
+        return counts_o
+
+
+def knn2_l2(q, t, ratio=0.65):
+    """Single pair: cv2.BFMatcher().knnMatch(q, t, k=2) + Lowe ratio.
+    q, t: (n,d) uint8 or integer-valued float32 (numpy or tensor).  Returns idx (nq,2) int32,
+    dist (nq,2) float32, good_count (int32 0-d tensor), all on the device."""
+    nq = 0 if q is None else q.shape[0]
+    nt = 0 if t is None else t.shape[0]
+    if nq == 0 or nt == 0:
+        raise IsxError("knn2_l2 needs non-empty query and train sets (the reference returns [] before matching)")
+    P = prepare_descriptors([q, t])
+    items = np.array([[P.starts[0], nq, P.starts[1], nt]], np.int32)
+    counts, (idx, dist, _) = knn2_l2_items(P, items, ratio, want_matches=True, xcd_order=False)
+    return idx, dist, counts[0]

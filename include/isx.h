@@ -1,0 +1,94 @@
+/*
+ * include/isx.h -- C ABI of libisx_hip.so, the MI355X (gfx950) stitching core.
+ *
+ * The reference (codegallivant/image-stitcher v0.9.1) is pure Python and has NO plugin / FFI
+ * interface: its hot path is seven overridable `Stitcher` methods that call cv2 and numpy.  Each entry
+ * point below therefore cites the reference *method* (file:line, relative to
+ * /root/reference/image_stitcher/) whose arithmetic it replaces; INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer argument named *_dev is a raw DEVICE address (e.g. torch.Tensor.data_ptr());
+ *     every pointer named *_host is a host address;
+ *   - the caller owns every buffer; the library allocates nothing it returns;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is queued on it and
+ *     the call returns without synchronising unless stated otherwise;
+ *   - every function returns 0 on success or a negative isx_status; isx_last_error() returns a
+ *     thread-local human readable message for the last failure on the calling thread;
+ *   - there is no CPU fallback: without a HIP device the compute entry points fail with ISX_E_HIP.
+ */
+#ifndef ISX_H
+#define ISX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum isx_status {
+    ISX_OK = 0,
+    ISX_E_ARG = -1,         /* invalid argument */
+    ISX_E_HIP = -2,         /* a HIP runtime call failed (message has the hipError string) */
+    ISX_E_UNSUPPORTED = -3, /* valid request this build has no kernel for (message says which) */
+    ISX_E_RANGE = -4        /* data outside the exact-arithmetic range of the requested path */
+};
+
+enum isx_dtype { ISX_U8 = 0, ISX_F32 = 1 };
+enum isx_norm { ISX_NORM_L2 = 0, ISX_NORM_HAMMING = 1 };
+enum isx_model { ISX_MODEL_AFFINE_PARTIAL = 0, ISX_MODEL_HOMOGRAPHY = 1 }; /* stitcher.py:137-140 `type` */
+enum isx_blender { ISX_BLEND_ALPHA = 0, ISX_BLEND_GRADIENT = 1 };          /* stitcher.py:153-156 `blender` */
+
+int isx_version(void);
+const char *isx_last_error(void);
+/* number of HIP devices visible (0 if none / no driver).  Never fails. */
+int isx_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Descriptor matching.   Replaces Stitcher.get_matches + Stitcher.filter_matches
+ * (stitcher.py:106-116 `matcher_obj.knnMatch(des1, des2, k=2)` with matcher_obj = cv2.BFMatcher()
+ * built at stitcher.py:85, and stitcher.py:118-127 Lowe ratio test) and the all-pairs loop body of
+ * ArbitraryStitcher.get_collections (stitcher.py:285-296).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Padded descriptor width the integer L2 path uses for a descriptor of `d` bytes (32, 64 or 128;
+ * negative status if d is unsupported). */
+int isx_desc_pad(int d);
+
+/* Prepare `rows` descriptors for the exact integer-L2 matcher.
+ *   src_dev   : rows x d, row-major, uint8 (ISX_U8) or float32 (ISX_F32, must be integer valued in
+ *               [0,255] -- what cv2.SIFT returns; anything else raises flag bit 0)
+ *   desc_dev  : rows x isx_desc_pad(d) int8   (value - 128, zero padded)
+ *   cbase_dev : rows uint32                   ((BIAS - ||v-128||^2) << 8, the per-train-row key base)
+ *   nrm_dev   : rows int32                    (||v-128||^2)
+ *   stats_dev : 2 int32, caller-zeroed: [0] |= 1 if a float value was not an integer in [0,255];
+ *               [1] = max over rows of ||v||^2 (atomicMax) -- the caller checks 2*max < ISX_L2_EXACT_LIMIT
+ */
+#define ISX_L2_EXACT_LIMIT 4197200 /* sqrtf is injective on integers below this (verified exhaustively) */
+int isx_desc_prep(const void *src_dev, int src_dtype, int64_t rows, int d, int8_t *desc_dev,
+                  uint32_t *cbase_dev, int32_t *nrm_dev, int32_t *stats_dev, void *stream);
+
+/* One matching work item: query rows [q_start, q_start+nq) against train rows [t_start, t_start+nt)
+ * of the prepared arrays. */
+typedef struct isx_knn_item {
+    int32_t q_start, nq, t_start, nt;
+} isx_knn_item;
+
+/* Batched exact kNN-2 (L2 over integer descriptors, distances = sqrtf(int), ties -> lowest train index
+ * in both slots, exactly cv2.BFMatcher(NORM_L2).knnMatch(k=2)) fused with the Lowe ratio test.
+ *   items_dev     : n_items work items (device)
+ *   max_nq        : max over items of nq (host value; sizes the grid)
+ *   ratio         : lowes_ratio_threshold, compared in float64 as the reference's Python does
+ *   idx_out_dev   : optional (may be NULL) int32 [(out_start[e]+i)*2 + k], -1 = absent
+ *   dist_out_dev  : optional float32, same indexing (FLT_MAX where absent)
+ *   out_start_dev : int64 per item, first output row of the item (required iff idx/dist given)
+ *   count_out_dev : optional int32 per item, MUST be zeroed by the caller; receives len(good_matches)
+ */
+int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_dev, const int32_t *nrm_dev,
+                      int d_pad, const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
+                      int32_t *idx_out_dev, float *dist_out_dev, const int64_t *out_start_dev,
+                      int32_t *count_out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
