@@ -40,6 +40,9 @@ def lib():
             raise IsxError(
                 f"{LIB_PATH} is missing: build it with `python image-stitcher_amd/build.py` "
                 "(there is no CPU fallback for the stitching core)")
+        # torch bundles its own libamdhip64; it must be the HIP runtime this process binds first,
+        # otherwise two runtimes fight over the device ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -124,28 +124,49 @@ def order_items_for_xcd(items):
     return out, perm
 
 
-def knn2_l2_items(P, items, ratio, want_matches=False, xcd_order=True):
+def plan_items(items, device, xcd_order=True):
+    """Host-side launch plan for an item list: XCD-aware order, device copy, inverse permutation."""
+    items = np.ascontiguousarray(np.asarray(items, np.int32).reshape(-1, 4))
+    n = len(items)
+    if xcd_order and n > 8:
+        run_items, perm = order_items_for_xcd(items)
+        valid = perm >= 0
+        inv_np = np.empty((n,), np.int64)
+        inv_np[perm[valid]] = np.nonzero(valid)[0]
+        inv_dev = torch.from_numpy(inv_np).to(device)
+    else:
+        run_items, perm, inv_np, inv_dev = items, np.arange(n), None, None
+    items_dev = torch.from_numpy(run_items).to(device)
+    return run_items, perm, items_dev, inv_dev, inv_np
+
+
+def knn2_l2_items(P, items, ratio, want_matches=False, xcd_order=True, plan=None, events=None):
     """Run the fused kNN-2 + ratio kernel over directed work items.
 
     items: (n,4) int32 rows (q_start, nq, t_start, nt) into P's row space.
+    plan: optional result of plan_items(items) (cached reordering + device copy of the item list).
+    events: optional (start, end) torch.cuda.Event pair recorded immediately around the kernel launch
+    on the launch stream (what bench.py uses for the per-launch kernel duration).
     Returns counts (n,) int32 device tensor [len(good_matches) per item] and, if want_matches,
     (idx, dist, out_starts): idx/dist are (sum nq, 2) device tensors, out_starts (n,) numpy int64.
     """
     L = _lib.lib()
-    items = np.ascontiguousarray(np.asarray(items, np.int32).reshape(-1, 4))
-    n = len(items)
+    if plan is not None:
+        n = len(plan[4]) if plan[4] is not None else len(plan[0])
+    else:
+        items = np.ascontiguousarray(np.asarray(items, np.int32).reshape(-1, 4))
+        n = len(items)
     dev = P.device
     with torch.cuda.device(dev):
         if n == 0:
             z = torch.zeros((0,), dtype=torch.int32, device=dev)
             return (z, None) if want_matches else z
-        if xcd_order and n > 8:
-            run_items, perm = order_items_for_xcd(items)
-        else:
-            run_items, perm = items, np.arange(n)
+        if plan is None:
+            plan = plan_items(items, dev, xcd_order)
+        run_items, perm, items_dev, inv_dev, inv_np = plan
+        reordered = inv_np is not None
         m = len(run_items)
         max_nq = int(run_items[:, 1].max())
-        items_dev = torch.from_numpy(run_items).to(dev, non_blocking=True)
         counts = torch.zeros((m,), dtype=torch.int32, device=dev)
         idx = dist = out_dev = None
         out_starts = None
@@ -155,14 +176,15 @@ def knn2_l2_items(P, items, ratio, want_matches=False, xcd_order=True):
             idx = torch.empty((total, 2), dtype=torch.int32, device=dev)
             dist = torch.empty((total, 2), dtype=torch.float32, device=dev)
             out_dev = torch.from_numpy(out_run[:-1].copy()).to(dev, non_blocking=True)
+        if events is not None:
+            events[0].record()
         check(L.isx_knn2_l2_items(_ptr(P.desc), _ptr(P.cbase), _ptr(P.nrm), P.d_pad, _ptr(items_dev), m,
                                   max_nq, float(ratio), _ptr(idx), _ptr(dist), _ptr(out_dev),
                                   _ptr(counts), _stream()))
-        if xcd_order and n > 8:
-            valid = perm >= 0
-            inv_np = np.empty((n,), np.int64)
-            inv_np[perm[valid]] = np.nonzero(valid)[0]
-            counts_o = counts[torch.from_numpy(inv_np).to(dev)]
+        if events is not None:
+            events[1].record()
+        if reordered:
+            counts_o = counts[inv_dev]
             if want_matches:
                 out_starts = out_run[:-1][inv_np]
         else:

@@ -1,0 +1,80 @@
+"""All-pairs relation graph of ArbitraryStitcher.get_collections (reference stitcher.py:280-304),
+sharded over the GPUs of one node.
+
+The reference evaluates every ORDERED pair (i, j), i != j (optionally |i-j| <= consecutive_range,
+stitcher.py:289-291) with knnMatch + ratio test and unions i, j when len(good) >= min_match_count.
+Here the unordered pair list {i<j} is dealt round-robin to the ranks (pair p -> rank p % world),
+every rank runs both directions of its pairs in ONE kernel launch, and only the int32 good-match
+counts travel back.  Collectives (RCCL when the tensors are on GPU, gloo in the CPU tests):
+    all_gather  of the per-rank descriptor shards   (only when detection was sharded)
+    gather      of the per-pair counts to rank 0
+"""
+import numpy as np
+import torch
+
+from .utils.structs import DynamicConnectivity
+
+
+def unordered_pairs(n, consecutive_range=None):
+    """(p,2) int64 array of i<j pairs in the reference's visiting order restricted to i<j."""
+    i, j = np.triu_indices(n, 1)
+    if consecutive_range is not None:
+        keep = (j - i) <= consecutive_range
+        i, j = i[keep], j[keep]
+    return np.stack([i, j], 1).astype(np.int64)
+
+
+def shard_pairs(pairs, rank, world):
+    """pair p -> rank p % world (uniform cost mix on every rank)."""
+    return pairs[rank::world]
+
+
+def directed_items(pairs, starts, counts):
+    """Both directions of every unordered pair as kernel work items (q_start, nq, t_start, nt).
+    Row 2p is i->j, row 2p+1 is j->i."""
+    i, j = pairs[:, 0], pairs[:, 1]
+    it = np.empty((2 * len(pairs), 4), np.int32)
+    it[0::2, 0], it[0::2, 1], it[0::2, 2], it[0::2, 3] = starts[i], counts[i], starts[j], counts[j]
+    it[1::2, 0], it[1::2, 1], it[1::2, 2], it[1::2, 3] = starts[j], counts[j], starts[i], counts[i]
+    return it
+
+
+def components_from_counts(n, pairs, counts_ij, counts_ji, min_match_count, n_union_find=None):
+    """Host union-find exactly as stitcher.py:283-300: the reference visits ordered pairs in (i, j)
+    lexicographic order; the component LISTS do not depend on union order (members are listed
+    ascending, components ordered by smallest member, then stable-sorted by length descending).
+    n_union_find: the reference sizes the union-find BEFORE dropping empty images (stitcher.py:283)."""
+    dc = DynamicConnectivity(n if n_union_find is None else n_union_find)
+    ok = (np.asarray(counts_ij) >= min_match_count) | (np.asarray(counts_ji) >= min_match_count)
+    for (i, j) in pairs[ok]:
+        dc.union(int(i), int(j))
+    comps = dc.get_connected_components()
+    comps = sorted(comps, key=len, reverse=True)
+    return comps, dc
+
+
+def all_gather_descriptors(local_des, group=None):
+    """local_des: (n_local, kp, d) uint8 tensor (equal shapes on every rank).  Returns (n, kp, d)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local_des
+    out = torch.empty((world,) + tuple(local_des.shape), dtype=local_des.dtype, device=local_des.device)
+    dist.all_gather_into_tensor(out, local_des.contiguous(), group=group)
+    return out.reshape((-1,) + tuple(local_des.shape[1:]))
+
+
+def gather_counts(local_counts, n_pairs_total, rank, world, group=None):
+    """local_counts: (p_local, 2) int32 for pairs rank::world.  Rank 0 returns (n_pairs_total, 2); others None."""
+    import torch.distributed as dist
+    if world == 1:
+        return local_counts
+    per = (n_pairs_total + world - 1) // world
+    pad = torch.zeros((per, 2), dtype=torch.int32, device=local_counts.device)
+    pad[:local_counts.shape[0]] = local_counts
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    allc = torch.stack(bufs, 1).reshape(-1, 2)  # row q*world + r  <- rank r's q-th pair = pair q*world + r
+    return allc[:n_pairs_total]
