@@ -23,6 +23,15 @@ SIGNATURES = {
     "isx_desc_prep": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isx_knn2_l2_items": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "isx_bbox_nonzero": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
+    "isx_bbox_reset": (c_int, [c_void_p, c_void_p]),
+    "isx_warp": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64,
+                         c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isx_alpha_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
+                                c_double, c_void_p]),
+    "isx_gradient_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+                                   c_void_p]),
+    "isx_copy2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_void_p]),
 }
 
 

@@ -208,3 +208,104 @@ def knn2_l2(q, t, ratio=0.65):
     items = np.array([[P.starts[0], nq, P.starts[1], nt]], np.int32)
     counts, (idx, dist, _) = knn2_l2_items(P, items, ratio, want_matches=True, xcd_order=False)
     return idx, dist, counts[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# image space
+# ---------------------------------------------------------------------------------------------
+def _img_args(t, name="image"):
+    """(ptr, h, w, c, pitch) of a uint8 device image (H,W) or (H,W,C); rows may be strided (views)."""
+    _require_cuda(t, name)
+    if t.dtype != torch.uint8 or t.ndim not in (2, 3):
+        raise IsxError(f"{name} must be a uint8 (H,W) or (H,W,C) tensor")
+    h, w = t.shape[0], t.shape[1]
+    c = 1 if t.ndim == 2 else t.shape[2]
+    if c not in (1, 3):
+        raise IsxError(f"{name}: channels must be 1 or 3 (got {c}); the reference's pad_image raises too")
+    if h > 0 and w > 0:
+        ok = (t.stride(1) == c) and (t.ndim == 2 or t.stride(2) == 1) and (t.stride(0) >= w * c or h == 1)
+        if not ok:
+            raise IsxError(f"{name} must have contiguous pixels within a row (strides {t.stride()})")
+    pitch = t.stride(0) if h > 1 else max(w * c, t.stride(0))
+    return _ptr(t), h, w, c, pitch
+
+
+def bbox_nonzero(img):
+    """get_corners_from_image on the device: int32[5] tensor {x0,y0,x1,y1,found} (no sync)."""
+    p, h, w, c, pitch = _img_args(img)
+    with torch.cuda.device(img.device):
+        bb = torch.empty((5,), dtype=torch.int32, device=img.device)
+        check(_lib.lib().isx_bbox_nonzero(p, h, w, c, pitch, _ptr(bb), _stream()))
+    return bb
+
+
+def bbox_to_corners(bb_host):
+    """numpy int32[5] -> ((x0,y0),(x1,y1)) or False, the reference's get_corners_from_image contract."""
+    if not bb_host[4]:
+        return False
+    return ((int(bb_host[0]), int(bb_host[1])), (int(bb_host[2]), int(bb_host[3])))
+
+
+def warp(src, M, perspective, dst_rect, src_xy=(0, 0), out=None, bbox=None):
+    """cv2.warpAffine / cv2.warpPerspective (INTER_LINEAR, constant 0) of `src` placed at src_xy of a
+    virtual canvas, producing canvas rectangle dst_rect = (x0, y0, w, h).  M: forward 2x3 / 3x3 float64.
+    bbox: optional int32[5] accumulator tensor (gray != 0 bbox of the produced pixels)."""
+    p, sh, sw, c, spitch = _img_args(src, "src")
+    x0, y0, dw, dh = (int(v) for v in dst_rect)
+    M = np.ascontiguousarray(M, np.float64)
+    if M.shape != ((3, 3) if perspective else (2, 3)):
+        raise IsxError(f"M has shape {M.shape}")
+    with torch.cuda.device(src.device):
+        if out is None:
+            out = torch.empty((dh, dw) + ((c,) if src.ndim == 3 else ()), dtype=torch.uint8, device=src.device)
+        po, oh, ow, oc, opitch = _img_args(out, "out")
+        if (oh, ow, oc) != (dh, dw, c):
+            raise IsxError("out does not match dst_rect")
+        check(_lib.lib().isx_warp(p, sh, sw, c, spitch, int(src_xy[0]), int(src_xy[1]),
+                                  M.ctypes.data_as(ctypes.c_void_p),
+                                  _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL,
+                                  po, opitch, x0, y0, dw, dh, _ptr(bbox), _stream()))
+    return out
+
+
+def new_bbox(device):
+    with torch.cuda.device(device):
+        bb = torch.empty((5,), dtype=torch.int32, device=device)
+        check(_lib.lib().isx_bbox_reset(_ptr(bb), _stream()))
+    return bb
+
+
+def alpha_blend(warped, ref, contrib, out=None):
+    """seamless_merge(image1=warped, image2=ref, contrib); out may be ref itself (in place)."""
+    pw, h, w, c, wp = _img_args(warped, "warped")
+    pr, h2, w2, c2, rp = _img_args(ref, "ref")
+    if (h, w, c) != (h2, w2, c2):
+        raise IsxError("warped and ref differ in shape")
+    with torch.cuda.device(ref.device):
+        if out is None:
+            out = torch.empty_like(ref, memory_format=torch.contiguous_format)
+        po, h3, w3, c3, op = _img_args(out, "out")
+        check(_lib.lib().isx_alpha_blend(pw, wp, pr, rp, po, op, h, w, c, float(contrib), _stream()))
+    return out
+
+
+def gradient_blend_roi(warped_roi, ref_roi, feather=10):
+    """ROI body of seamless_gradient_merge; ref_roi is updated in place."""
+    pw, h, w, c, wp = _img_args(warped_roi, "warped_roi")
+    pr, h2, w2, c2, rp = _img_args(ref_roi, "ref_roi")
+    if (h, w, c) != (h2, w2, c2):
+        raise IsxError("warped_roi and ref_roi differ in shape")
+    with torch.cuda.device(ref_roi.device):
+        ext = torch.empty((2 * h + 2 * w,), dtype=torch.int32, device=ref_roi.device)
+        check(_lib.lib().isx_gradient_blend(pw, wp, pr, rp, h, w, c, int(feather), _ptr(ext), _stream()))
+    return ref_roi
+
+
+def copy2d(src, dst):
+    ps, h, w, c, sp = _img_args(src, "src")
+    pd, h2, w2, c2, dp = _img_args(dst, "dst")
+    if (h, w, c) != (h2, w2, c2):
+        raise IsxError("copy2d shape mismatch")
+    with torch.cuda.device(dst.device):
+        check(_lib.lib().isx_copy2d(ps, sp, pd, dp, h, w * c, _stream()))
+    return dst

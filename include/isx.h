@@ -88,6 +88,45 @@ int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_dev, const i
                       int32_t *idx_out_dev, float *dist_out_dev, const int64_t *out_start_dev,
                       int32_t *count_out_dev, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Image space.  All images: uint8, interleaved channels (c = 1 or 3), PITCHED: `pitch` is the row
+ * stride in bytes, so a crop / ROI of a device image is a pointer to its first pixel + the parent pitch.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Replaces get_corners_from_image (utils/proc.py:34-45: cv2.cvtColor(BGR2GRAY) -> cv2.findNonZero ->
+ * cv2.boundingRect), also the bbox half of crop_image (utils/proc.py:307-312).
+ * bbox_out_dev: 5 int32 {x0, y0, x1, y1 (exclusive), found}; found == 0 <=> the reference returns False. */
+int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int64_t pitch, int32_t *bbox_out_dev,
+                     void *stream);
+/* Re-initialise a bbox accumulator (for isx_warp's accumulating bbox output). */
+int isx_bbox_reset(int32_t *bbox_dev, void *stream);
+
+/* Replaces Stitcher.warp_target (stitcher.py:143-149: cv2.warpAffine / cv2.warpPerspective with
+ * INTER_LINEAR, BORDER_CONSTANT 0, dsize = padded canvas) for a source that is the UN-padded frame
+ * sitting at (src_x, src_y) of the virtual padded canvas of get_padded_images (utils/proc.py:295-304).
+ * Produces only the canvas rectangle [dx0,dx0+dw) x [dy0,dy0+dh) into dst_dev (its first pixel).
+ *   M_host : forward map, 6 doubles (model ISX_MODEL_AFFINE_PARTIAL, 2x3) or 9 doubles (3x3)
+ *   bbox_out_dev : optional 5-int accumulator (see isx_bbox_reset) that receives the bbox, in canvas
+ *                  coordinates, of produced pixels whose gray != 0  (stitcher.py:220) */
+int isx_warp(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
+             const double *M_host, int model, uint8_t *dst_dev, int64_t dpitch, int dx0, int dy0, int dw,
+             int dh, int32_t *bbox_out_dev, void *stream);
+
+/* Replaces seamless_merge (utils/proc.py:48-82; Stitcher.merge blender=0, stitcher.py:153-154).
+ * warped/ref/out are same-size views; out may alias ref. */
+int isx_alpha_blend(const uint8_t *warped_dev, int64_t wpitch, const uint8_t *ref_dev, int64_t rpitch,
+                    uint8_t *out_dev, int64_t opitch, int h, int w, int c, double ref_contrib, void *stream);
+
+/* Replaces the ROI body of seamless_gradient_merge (utils/proc.py:207-253; Stitcher.merge blender=1).
+ * warped/ref are the two ROI views the reference cuts at proc.py:199-205 (bbox(warped) +- 50 px clipped
+ * to the canvas); ref is updated in place.  ext_dev: caller scratch of 2*h + 2*w int32. */
+int isx_gradient_blend(const uint8_t *warped_dev, int64_t wpitch, uint8_t *ref_dev, int64_t rpitch, int h, int w,
+                       int c, int feather, int32_t *ext_dev, void *stream);
+
+/* Pitched device-to-device copy (mosaic arena growth / get_padded_images paste, utils/proc.py:290-291). */
+int isx_copy2d(const uint8_t *src_dev, int64_t spitch, uint8_t *dst_dev, int64_t dpitch, int h,
+               int64_t row_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

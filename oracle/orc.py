@@ -82,3 +82,73 @@ def match_count(q, t, ratio, norm=NORM_L2, nthreads=1):
                                         ctypes.c_double(ratio), nthreads)
     return lib().orc_match_count_f32(_p(q), q.shape[0], _p(t), t.shape[0], q.shape[1],
                                      ctypes.c_double(ratio), nthreads)
+
+
+# ---------------------------------------------------------------------------------------------
+# image space (oracle/orc_image.c)
+# ---------------------------------------------------------------------------------------------
+def _img(a):
+    a = np.ascontiguousarray(a, np.uint8)
+    h, w = a.shape[:2]
+    c = 1 if a.ndim == 2 else a.shape[2]
+    return a, h, w, c
+
+
+def bgr2gray(img):
+    a, h, w, c = _img(img)
+    assert c == 3
+    out = np.empty((h, w), np.uint8)
+    lib().orc_bgr2gray(_p(a), h, w, _p(out))
+    return out
+
+
+def bbox_nonzero(img):
+    """get_corners_from_image: ((x0,y0),(x1,y1)) or False"""
+    a, h, w, c = _img(img)
+    bb = np.zeros(4, np.int32)
+    lib().orc_bbox_nonzero.restype = ctypes.c_int
+    if not lib().orc_bbox_nonzero(_p(a), h, w, c, _p(bb)):
+        return False
+    return ((int(bb[0]), int(bb[1])), (int(bb[2]), int(bb[3])))
+
+
+def pad_image(img, new_h, new_w):
+    a, h, w, c = _img(img)
+    out = np.empty((new_h, new_w) + ((c,) if a.ndim == 3 else ()), np.uint8)
+    lib().orc_pad_image(_p(a), h, w, c, new_h, new_w, _p(out))
+    return out
+
+
+def get_padded_images(img, ref):
+    """proc.py:295-304 (channels taken from img)."""
+    new_w = ref.shape[1] + 2 * img.shape[1]
+    new_h = ref.shape[0] + 2 * img.shape[0]
+    return pad_image(img, new_h, new_w), pad_image(ref, new_h, new_w)
+
+
+def warp(src, M, dsize_wh, perspective, arith=0):
+    a, sh, sw, c = _img(src)
+    dw, dh = dsize_wh
+    M = np.ascontiguousarray(M, np.float64)
+    assert M.shape == ((3, 3) if perspective else (2, 3))
+    out = np.empty((dh, dw) + ((c,) if a.ndim == 3 else ()), np.uint8)
+    lib().orc_warp(_p(a), sh, sw, c, _p(M), int(bool(perspective)), _p(out), dh, dw, arith)
+    return out
+
+
+def alpha_blend(warped, ref, contrib):
+    a, h, w, c = _img(warped)
+    b, h2, w2, c2 = _img(ref)
+    assert (h, w, c) == (h2, w2, c2)
+    out = np.empty_like(a)
+    lib().orc_alpha_blend(_p(a), _p(b), h, w, c, ctypes.c_double(contrib), _p(out))
+    return out
+
+
+def gradient_blend(warped, ref, feather=10):
+    """Returns the modified copy of ref (the reference mutates its argument)."""
+    a, h, w, c = _img(warped)
+    b = np.array(ref, dtype=np.uint8, order="C", copy=True)
+    assert b.shape == a.shape
+    lib().orc_gradient_blend(_p(a), _p(b), h, w, c, feather)
+    return b
