@@ -152,3 +152,99 @@ def gradient_blend(warped, ref, feather=10):
     assert b.shape == a.shape
     lib().orc_gradient_blend(_p(a), _p(b), h, w, c, feather)
     return b
+
+
+# ---------------------------------------------------------------------------------------------
+# robust transform (oracle/orc_ransac.c)
+# ---------------------------------------------------------------------------------------------
+def _pts(p):
+    return np.ascontiguousarray(np.asarray(p, np.float32).reshape(-1, 2))
+
+
+def _msz(model):
+    return 9 if model == MODEL_HOMOGRAPHY else 6
+
+
+def _mshape(model):
+    return (3, 3) if model == MODEL_HOMOGRAPHY else (2, 3)
+
+
+def ransac_sample(model, src, dst, max_iters=2000):
+    s, d = _pts(src), _pts(dst)
+    mp = 4 if model == MODEL_HOMOGRAPHY else 2
+    out = np.zeros((max_iters, mp), np.int32)
+    lib().orc_ransac_sample.restype = ctypes.c_int
+    k = lib().orc_ransac_sample(model, _p(s), _p(d), len(s), max_iters, _p(out))
+    return out[:k]
+
+
+def fit_model(model, src, dst):
+    s, d = _pts(src), _pts(dst)
+    M = np.zeros(_msz(model), np.float64)
+    lib().orc_fit_model.restype = ctypes.c_int
+    ok = lib().orc_fit_model(model, _p(s), _p(d), len(s), _p(M))
+    return M.reshape(_mshape(model)) if ok else None
+
+
+def reproj_err(model, M, src, dst):
+    s, d = _pts(src), _pts(dst)
+    M = np.ascontiguousarray(M, np.float64)
+    err = np.empty(len(s), np.float32)
+    lib().orc_reproj_err(model, _p(M), _p(s), _p(d), len(s), _p(err))
+    return err
+
+
+def score(model, M, src, dst, thr):
+    s, d = _pts(src), _pts(dst)
+    M = np.ascontiguousarray(M, np.float64)
+    mask = np.empty(len(s), np.uint8)
+    lib().orc_score.restype = ctypes.c_int
+    n = lib().orc_score(model, _p(M), _p(s), _p(d), len(s), ctypes.c_double(thr), _p(mask))
+    return n, mask
+
+
+def find_homography(src, dst, thr=5.0, max_iters=2000, confidence=0.995):
+    """cv2.findHomography(src, dst, cv2.RANSAC, 5.0) -> (M 3x3 | None, mask (n,1) uint8)"""
+    s, d = _pts(src), _pts(dst)
+    M = np.zeros(9, np.float64)
+    mask = np.zeros(len(s), np.uint8)
+    lib().orc_find_homography_ransac.restype = ctypes.c_int
+    ok = lib().orc_find_homography_ransac(_p(s), _p(d), len(s), ctypes.c_double(thr), max_iters,
+                                          ctypes.c_double(confidence), _p(M), _p(mask))
+    return (M.reshape(3, 3) if ok else None), mask.reshape(-1, 1)
+
+
+def estimate_affine_partial(src, dst, thr=3.0, max_iters=2000, confidence=0.99, refine_iters=10):
+    """cv2.estimateAffinePartial2D(src, dst) -> (M 2x3 | None, inliers (n,1) uint8)"""
+    s, d = _pts(src), _pts(dst)
+    M = np.zeros(6, np.float64)
+    mask = np.zeros(len(s), np.uint8)
+    lib().orc_estimate_affine_partial.restype = ctypes.c_int
+    ok = lib().orc_estimate_affine_partial(_p(s), _p(d), len(s), ctypes.c_double(thr), max_iters,
+                                           ctypes.c_double(confidence), refine_iters, _p(M), _p(mask))
+    return (M.reshape(2, 3) if ok else None), mask.reshape(-1, 1)
+
+
+def ransac_trace(model, src, dst, thr, max_iters=2000, confidence=None):
+    """Every hypothesis the sequential RANSAC tries, in order: (hyps (k,msz), counts (k,), valid (k,), best_iter)."""
+    if confidence is None:
+        confidence = 0.995 if model == MODEL_HOMOGRAPHY else 0.99
+    s, d = _pts(src), _pts(dst)
+    hyp = np.zeros((max_iters, _msz(model)), np.float64)
+    cnt = np.zeros(max_iters, np.int32)
+    valid = np.zeros(max_iters, np.int32)
+    n_iter = ctypes.c_int(0)
+    best = ctypes.c_int(-1)
+    lib().orc_ransac_trace.restype = ctypes.c_int
+    ok = lib().orc_ransac_trace(model, _p(s), _p(d), len(s), ctypes.c_double(thr), max_iters,
+                                ctypes.c_double(confidence), _p(hyp), _p(cnt), _p(valid),
+                                ctypes.byref(n_iter), ctypes.byref(best))
+    k = n_iter.value
+    return bool(ok), hyp[:k], cnt[:k], valid[:k], best.value
+
+
+def refine(model, M, src_inl, dst_inl, refit, max_iters=10):
+    s, d = _pts(src_inl), _pts(dst_inl)
+    M = np.array(M, np.float64).reshape(-1).copy()
+    lib().orc_refine(model, _p(s), _p(d), len(s), int(refit), max_iters, _p(M))
+    return M.reshape(_mshape(model))
