@@ -32,6 +32,13 @@ SIGNATURES = {
     "isx_gradient_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p]),
     "isx_copy2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "isx_ransac_sample": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "isx_ransac_hypotheses": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "isx_ransac_score": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p,
+                                 c_void_p]),
+    "isx_ransac_select": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_double, c_int, c_void_p, c_void_p]),
+    "isx_ransac_refine": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_int, c_void_p,
+                                  c_void_p, c_void_p]),
 }
 
 

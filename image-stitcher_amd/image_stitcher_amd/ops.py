@@ -309,3 +309,122 @@ def copy2d(src, dst):
     with torch.cuda.device(dst.device):
         check(_lib.lib().isx_copy2d(ps, sp, pd, dp, h, w * c, _stream()))
     return dst
+
+
+# ---------------------------------------------------------------------------------------------
+# robust transform (Stitcher.get_transform, reference stitcher.py:135-141)
+# ---------------------------------------------------------------------------------------------
+# cv2 defaults of the two calls the reference makes
+RANSAC_DEFAULTS = {
+    False: dict(thr=3.0, max_iters=2000, confidence=0.99, refine_iters=10),   # estimateAffinePartial2D
+    True: dict(thr=5.0, max_iters=2000, confidence=0.995, refine_iters=10),   # findHomography(RANSAC, 5.0)
+}
+
+
+def ransac_sample(src, dst, perspective, max_iters=2000):
+    """Host: the subset sequence cv's RANSAC would draw (k, 4|2) int32."""
+    model = _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL
+    s = np.ascontiguousarray(np.asarray(src, np.float32).reshape(-1, 2))
+    d = np.ascontiguousarray(np.asarray(dst, np.float32).reshape(-1, 2))
+    mp = 4 if perspective else 2
+    out = np.zeros((max(max_iters, 1), mp), np.int32)
+    k = check(_lib.lib().isx_ransac_sample(model, s.ctypes.data_as(ctypes.c_void_p), d.ctypes.data_as(ctypes.c_void_p),
+                                           len(s), max_iters, out.ctypes.data_as(ctypes.c_void_p)))
+    return out[:k]
+
+
+def ransac_hypotheses(src_dev, dst_dev, subsets_dev, perspective):
+    model = _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL
+    k = subsets_dev.shape[0]
+    dev = src_dev.device
+    with torch.cuda.device(dev):
+        models = torch.empty((k, 9 if perspective else 6), dtype=torch.float64, device=dev)
+        valid = torch.empty((k,), dtype=torch.int32, device=dev)
+        check(_lib.lib().isx_ransac_hypotheses(model, _ptr(src_dev), _ptr(dst_dev), src_dev.shape[0], _ptr(subsets_dev),
+                                               k, _ptr(models), _ptr(valid), _stream()))
+    return models, valid
+
+
+def ransac_score(models_dev, valid_dev, src_dev, dst_dev, perspective, thr):
+    model = _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL
+    k = models_dev.shape[0]
+    dev = src_dev.device
+    with torch.cuda.device(dev):
+        counts = torch.empty((k,), dtype=torch.int32, device=dev)
+        check(_lib.lib().isx_ransac_score(model, _ptr(models_dev), k, _ptr(valid_dev), _ptr(src_dev), _ptr(dst_dev),
+                                          src_dev.shape[0], float(thr), _ptr(counts), _stream()))
+    return counts
+
+
+def ransac_select(counts, valid, n_points, perspective, confidence, max_iters):
+    model = _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL
+    counts = np.ascontiguousarray(counts, np.int32)
+    valid = np.ascontiguousarray(valid, np.int32)
+    best = ctypes.c_int32(-1)
+    iters = ctypes.c_int32(0)
+    check(_lib.lib().isx_ransac_select(model, counts.ctypes.data_as(ctypes.c_void_p),
+                                       valid.ctypes.data_as(ctypes.c_void_p), len(counts), n_points,
+                                       float(confidence), max_iters, ctypes.byref(best), ctypes.byref(iters)))
+    return best.value, iters.value
+
+
+def ransac_refine(M_dev, src_dev, dst_dev, perspective, thr, refit, max_iters):
+    """In place on M_dev (9|6 float64).  Returns (mask uint8 (n,), info int32 (1,)) device tensors."""
+    model = _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL
+    dev = src_dev.device
+    n = src_dev.shape[0]
+    with torch.cuda.device(dev):
+        mask = torch.empty((n,), dtype=torch.uint8, device=dev)
+        info = torch.zeros((1,), dtype=torch.int32, device=dev)
+        check(_lib.lib().isx_ransac_refine(model, _ptr(M_dev), _ptr(src_dev), _ptr(dst_dev), n, float(thr),
+                                           int(bool(refit)), int(max_iters), _ptr(mask), _ptr(info), _stream()))
+    return mask, info
+
+
+def estimate_transform(src_pts, dst_pts, perspective, device=None, return_trace=False):
+    """cv2.estimateAffinePartial2D(src, dst) (perspective=False) or
+    cv2.findHomography(src, dst, cv2.RANSAC, 5.0) (perspective=True).
+    src_pts/dst_pts: host float32 arrays of n points (any shape ending in 2, e.g. (n,1,2)).
+    Returns (M float64 (2,3)|(3,3) or None, mask uint8 (n,1))."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    cfg = RANSAC_DEFAULTS[bool(perspective)]
+    s = np.ascontiguousarray(np.asarray(src_pts, np.float32).reshape(-1, 2))
+    d = np.ascontiguousarray(np.asarray(dst_pts, np.float32).reshape(-1, 2))
+    n = len(s)
+    if len(d) != n:
+        raise IsxError("src_pts and dst_pts differ in length")
+    mp = 4 if perspective else 2
+    shape = (3, 3) if perspective else (2, 3)
+    none = (None, np.zeros((n, 1), np.uint8))
+    if n < mp:
+        return none
+    subsets = ransac_sample(s, d, perspective, cfg["max_iters"])
+    if len(subsets) == 0:
+        return none
+    with torch.cuda.device(device):
+        sd = torch.from_numpy(s).to(device)
+        dd = torch.from_numpy(d).to(device)
+        sub_dev = torch.from_numpy(np.ascontiguousarray(subsets)).to(device)
+        models, valid = ransac_hypotheses(sd, dd, sub_dev, perspective)
+        if n == mp:
+            # cv: direct solve, mask of ones, no refinement (findHomography: npoints == 4; affine: count == 2)
+            ok = bool(valid[0].item())
+            M = models[0].cpu().numpy().reshape(shape) if ok else None
+            return (M, np.ones((n, 1), np.uint8)) if ok else none
+        counts = ransac_score(models, valid, sd, dd, perspective, cfg["thr"])
+        counts_h = counts.cpu().numpy()
+        valid_h = valid.cpu().numpy()
+        best, iters = ransac_select(counts_h, valid_h, n, perspective, cfg["confidence"], cfg["max_iters"])
+        if best < 0:
+            return none
+        M_dev = models[best].clone()
+        mask, info = ransac_refine(M_dev, sd, dd, perspective, cfg["thr"], refit=perspective,
+                                   max_iters=cfg["refine_iters"])
+        M = M_dev.cpu().numpy().reshape(shape)
+        mask_h = mask.cpu().numpy().reshape(-1, 1)
+    if return_trace:
+        return M, mask_h, dict(models=models, valid=valid_h, counts=counts_h, best=best, iters=iters,
+                               subsets=subsets)
+    return M, mask_h

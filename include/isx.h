@@ -127,6 +127,44 @@ int isx_gradient_blend(const uint8_t *warped_dev, int64_t wpitch, uint8_t *ref_d
 int isx_copy2d(const uint8_t *src_dev, int64_t spitch, uint8_t *dst_dev, int64_t dpitch, int h,
                int64_t row_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Robust transform.  Replaces Stitcher.get_transform (stitcher.py:135-141):
+ *   type 0: cv2.estimateAffinePartial2D(src, dst)       (RANSAC thr 3.0, 2000 iters, conf 0.99, 10 LM iters)
+ *   type 1: cv2.findHomography(src, dst, cv2.RANSAC, 5.0) (2000 iters, conf 0.995, DLT refit + 10 LM iters)
+ * Points are float32 (x, y) pairs, n of them (the (G,1,2) arrays of Stitcher.get_pts, stitcher.py:129-133).
+ * The sequential cv loop is reproduced exactly by: sample (host) -> hypotheses (GPU) -> score (GPU) ->
+ * select (host, replays the in-order "strictly better wins" + adaptive stop) -> refine (GPU).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* HOST.  cv::RNG(-1)-faithful subset list: up to max_iters subsets of 4 (homography) or 2 (affine
+ * partial) distinct indices, each passing cv's checkSubset.  Returns the number of subsets written
+ * (>= 0; < max_iters only if 10000 attempts failed, as cv gives up) or a negative status. */
+int isx_ransac_sample(int model, const float *src_host, const float *dst_host, int n, int max_iters,
+                      int32_t *subsets_out_host);
+
+/* GPU.  One minimal model per subset: models_out_dev n_hyp x (9|6) float64 row-major, valid_out_dev n_hyp. */
+int isx_ransac_hypotheses(int model, const float *src_dev, const float *dst_dev, int n,
+                          const int32_t *subsets_dev, int n_hyp, double *models_out_dev,
+                          int32_t *valid_out_dev, void *stream);
+
+/* GPU.  Inlier count of every hypothesis (float32 reprojection error <= thr^2, cv computeError /
+ * findInliers).  valid_dev may be NULL. */
+int isx_ransac_score(int model, const double *models_dev, int n_hyp, const int32_t *valid_dev,
+                     const float *src_dev, const float *dst_dev, int n, double thr, int32_t *counts_out_dev,
+                     void *stream);
+
+/* HOST.  Replays RANSACPointSetRegistrator::run over the counts: best_out = index of the winning
+ * hypothesis (-1 = none), iters_out = iterations cv would have run. */
+int isx_ransac_select(int model, const int32_t *counts_host, const int32_t *valid_host, int n_hyp,
+                      int n_points, double confidence, int max_iters, int32_t *best_out, int32_t *iters_out);
+
+/* GPU.  M_io_dev (9|6 float64): in = winning hypothesis, out = refined model.  Writes the winner's
+ * inlier mask (n uint8) and info_out_dev[0] = inlier count.  refit != 0: all-inlier DLT first
+ * (findHomography); max_iters: LM iterations (10 in the reference's calls; 0 = none). */
+int isx_ransac_refine(int model, double *M_io_dev, const float *src_dev, const float *dst_dev, int n,
+                      double thr, int refit, int max_iters, uint8_t *mask_out_dev, int32_t *info_out_dev,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,98 @@
+"""GPU parity of the batched RANSAC (through the C ABI) vs the CPU oracle.
+Gates (BASELINE.json north_star): inlier-set agreement >= 99 % when scoring the oracle's own hypotheses
+(measured here: exact equality of counts, same float32 arithmetic); final M within 0.5 px RMS
+reprojection of the oracle's (measured: ~1e-6 px)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def apply_m(M, p):
+    M = np.vstack([M, [0, 0, 1]]) if M.shape[0] == 2 else M
+    q = np.c_[p, np.ones(len(p))] @ M.T
+    return q[:, :2] / q[:, 2:3]
+
+
+def make_case(n, seed, outlier_frac, persp):
+    rng = np.random.default_rng(seed)
+    th = np.deg2rad(rng.uniform(-6, 6))
+    s = rng.uniform(0.95, 1.05)
+    H = np.array([[s * np.cos(th), -s * np.sin(th), rng.uniform(-300, 300)],
+                  [s * np.sin(th), s * np.cos(th), rng.uniform(-200, 200)], [0, 0, 1.0]])
+    if persp:
+        H[2, :2] = rng.uniform(-5e-5, 5e-5, 2)
+    src = rng.uniform(0, 1920, (n, 2)).astype(np.float32)
+    dst = (apply_m(H, src.astype(np.float64)) + rng.normal(0, 0.5, (n, 2))).astype(np.float32)
+    k = int(n * outlier_frac)
+    dst[:k] = rng.uniform(0, 1920, (k, 2)).astype(np.float32)
+    p = rng.permutation(n)
+    return src[p], dst[p], H
+
+
+@pytest.mark.parametrize("persp", [False, True])
+@pytest.mark.parametrize("n,frac", [(12, 0.0), (150, 0.3), (900, 0.5), (3000, 0.6)])
+def test_estimate_transform_vs_oracle(cuda, orc, persp, n, frac):
+    import torch
+    from image_stitcher_amd import ops
+    src, dst, H = make_case(n, 17 * n + persp, frac, persp)
+    model = orc.MODEL_HOMOGRAPHY if persp else orc.MODEL_AFFINE_PARTIAL
+    cfg = ops.RANSAC_DEFAULTS[persp]
+    M, mask, tr = ops.estimate_transform(src.reshape(-1, 1, 2), dst.reshape(-1, 1, 2), persp, return_trace=True)
+    Mo, masko = (orc.find_homography(src, dst) if persp else orc.estimate_affine_partial(src, dst))
+    ok, hyps, cnt, valid, best_it = orc.ransac_trace(model, src, dst, cfg["thr"], cfg["max_iters"], cfg["confidence"])
+    assert M is not None and Mo is not None
+    # (1) scoring the ORACLE's hypotheses on the GPU: identical inlier counts
+    sd, dd = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+    got = ops.ransac_score(torch.from_numpy(hyps).cuda(), torch.from_numpy(valid).cuda(), sd, dd, persp, cfg["thr"]).cpu().numpy()
+    assert np.array_equal(got, cnt)
+    # (2) GPU minimal solves agree with the oracle's (different algorithm: Gauss-Jordan null vector vs Jacobi)
+    k = len(hyps)
+    gm = tr["models"][:k].cpu().numpy()
+    v = valid.astype(bool) & tr["valid"][:k].astype(bool)
+    assert (tr["valid"][:k] == valid).mean() > 0.99
+    scale = np.abs(hyps[v]).max(1, keepdims=True)
+    assert (np.abs(gm[v] - hyps[v]) / scale).max() < 1e-6
+    # (3) same winner, same number of iterations, same mask, same model
+    assert tr["best"] == best_it and tr["iters"] == k
+    assert np.array_equal(mask, masko)
+    inl = mask.ravel().astype(bool)
+    rms = np.sqrt(((apply_m(M, src[inl].astype(np.float64)) - apply_m(Mo, src[inl].astype(np.float64))) ** 2).sum(1).mean())
+    assert rms < 1e-3, rms        # gate is 0.5 px
+    assert np.allclose(M, Mo, rtol=1e-5, atol=1e-5)
+    # and it recovers the planted transform
+    rms_true = np.sqrt(((apply_m(M, src[inl].astype(np.float64)) - apply_m(H, src[inl].astype(np.float64))) ** 2).sum(1).mean())
+    assert rms_true < 0.5
+
+
+def test_small_and_degenerate(cuda, orc):
+    from image_stitcher_amd import ops
+    src, dst, H = make_case(4, 1, 0.0, True)
+    M, mask = ops.estimate_transform(src, dst, True)
+    Mo, _ = orc.find_homography(src, dst)
+    assert mask.all() and np.allclose(M, Mo, rtol=1e-7, atol=1e-7)
+    M, mask = ops.estimate_transform(src[:2], dst[:2], False)
+    Mo, _ = orc.estimate_affine_partial(src[:2], dst[:2])
+    assert mask.all() and np.allclose(M, Mo, rtol=1e-12, atol=1e-9)
+    assert ops.estimate_transform(src[:3], dst[:3], True)[0] is None
+    assert ops.estimate_transform(src[:1], dst[:1], False)[0] is None
+    p = np.full((30, 2), 7.0, np.float32)
+    assert ops.estimate_transform(p, p, True)[0] is None
+
+
+def test_refine_stage_alone(cuda, orc):
+    """findHomography's tail (all-inlier DLT + LM) and estimateAffinePartial2D's tail (LM) from a rough model."""
+    import torch
+    from image_stitcher_amd import ops
+    for persp in (True, False):
+        src, dst, H = make_case(400, 5 + persp, 0.0, persp)
+        model = orc.MODEL_HOMOGRAPHY if persp else orc.MODEL_AFFINE_PARTIAL
+        M0 = H.copy() if persp else H[:2].copy()
+        M0[0, 2] += 0.7
+        M0[1, 2] -= 0.4
+        Md = torch.from_numpy(M0.reshape(-1).copy()).cuda()
+        mask, info = ops.ransac_refine(Md, torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(), persp, 50.0,
+                                       refit=persp, max_iters=10)
+        assert int(info.item()) == 400 and mask.cpu().numpy().all()
+        Mo = orc.refine(model, M0, src, dst, refit=persp, max_iters=10)
+        assert np.allclose(Md.cpu().numpy().reshape(Mo.shape), Mo, rtol=1e-6, atol=1e-6)
