@@ -360,3 +360,59 @@ extern "C" int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_d
         hipLaunchKernelGGL((knn2_l2_kernel<1>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
     return isx_launch_status("knn2_l2_kernel");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stable compaction of the rows that pass the Lowe ratio test: Stitcher.filter_matches
+// (reference stitcher.py:118-127) as a list, in query order.  One workgroup walks the rows in chunks
+// of 1024 with a ballot/popcount prefix sum, so the output order equals the reference's append order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) ratio_compact_kernel(const int32_t *__restrict__ idx,
+                                                             const float *__restrict__ dist, int nq, double ratio,
+                                                             int32_t *__restrict__ good_q,
+                                                             int32_t *__restrict__ good_t,
+                                                             int32_t *__restrict__ count_out) {
+    __shared__ int wave_tot[16];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int start = 0; start < nq; start += 1024) {
+        const int i = start + tid;
+        bool good = false;
+        int t0 = -1;
+        if (i < nq) {
+            t0 = idx[2 * i];
+            const int t1 = idx[2 * i + 1];
+            if (t0 >= 0) good = t1 < 0 || (double)dist[2 * i] < ratio * (double)dist[2 * i + 1];
+        }
+        const unsigned long long b = __ballot(good);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(b);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; w++) off += wave_tot[w];
+        if (good) {
+            good_q[off + before] = i;
+            good_t[off + before] = t0;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += wave_tot[w];
+            base_s += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) count_out[0] = base_s;
+}
+
+extern "C" int isx_ratio_compact(const int32_t *idx_dev, const float *dist_dev, int nq, double ratio,
+                                 int32_t *good_q_out_dev, int32_t *good_t_out_dev, int32_t *count_out_dev,
+                                 void *stream) {
+    ISX_REQUIRE(nq >= 0, "negative nq");
+    ISX_REQUIRE(count_out_dev, "null count_out_dev");
+    ISX_REQUIRE(nq == 0 || (idx_dev && dist_dev && good_q_out_dev && good_t_out_dev), "null device pointer");
+    hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx_dev, dist_dev, nq, ratio,
+                       good_q_out_dev, good_t_out_dev, count_out_dev);
+    return isx_launch_status("ratio_compact_kernel");
+}

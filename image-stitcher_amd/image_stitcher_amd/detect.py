@@ -1,0 +1,83 @@
+"""Feature detection stays on the CPU (BASELINE.json north_star: "keypoint detection stays on the
+reference's cv2 SIFT/ORB so both paths see identical descriptors"; reference stitcher.py:92-100).
+
+  make_detector(algorithm)  -> cv2.SIFT_create() / ORB_create() / AKAZE_create() when cv2 is importable
+  NumpyOrbLite              -> a small numpy/scipy corner + BRIEF-style detector used by the tests and
+                               bench.py where cv2 is not installed (it is NOT part of the hot path)
+Any object with detectAndCompute(image, mask) -> (keypoints, descriptors) can be passed to the stitchers
+as `detector=`; keypoints need a mutable `.pt` (x, y) like cv2.KeyPoint.
+"""
+import numpy as np
+
+
+class KeyPoint:
+    __slots__ = ("pt", "response")
+
+    def __init__(self, x, y, response=0.0):
+        self.pt = (float(x), float(y))
+        self.response = response
+
+
+def make_detector(algorithm):
+    try:
+        import cv2
+    except ImportError as e:  # pragma: no cover - cv2 is absent in the build image
+        raise ImportError(
+            "cv2 is not installed: pass detector=<object with detectAndCompute> to the stitcher "
+            "(e.g. image_stitcher_amd.detect.NumpyOrbLite())") from e
+    return [cv2.SIFT_create, cv2.ORB_create, cv2.AKAZE_create][algorithm]()
+
+
+def _gray(img):
+    if img.ndim == 2:
+        return img
+    b, g, r = (img[..., k].astype(np.int32) for k in range(3))
+    return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
+
+
+class NumpyOrbLite:
+    """Harris corners + a fixed 256-pair BRIEF pattern on a blurred image -> (n,32) uint8 descriptors.
+    Deterministic; translation- and small-rotation-tolerant, which is all the synthetic streams need."""
+
+    def __init__(self, nfeatures=1500, patch=12, seed=7, nms=7):
+        from scipy import ndimage  # noqa: F401  (fail early if scipy is missing)
+        self.nfeatures, self.patch, self.nms = nfeatures, patch, nms
+        rng = np.random.Generator(np.random.PCG64(seed))
+        p = np.clip(np.rint(rng.normal(0, patch / 2.2, (256, 4))), -patch, patch).astype(np.int32)
+        self.pairs = p
+
+    def detectAndCompute(self, image, mask=None):
+        from scipy import ndimage
+        img = np.asarray(image)
+        g8 = _gray(img)
+        h, w = g8.shape
+        m = self.patch + 4
+        if h <= 2 * m + 2 or w <= 2 * m + 2:
+            return [], None
+        g = ndimage.gaussian_filter(g8.astype(np.float32), 2.0)
+        ix = ndimage.sobel(g, axis=1)
+        iy = ndimage.sobel(g, axis=0)
+        sxx = ndimage.gaussian_filter(ix * ix, 2.0)
+        syy = ndimage.gaussian_filter(iy * iy, 2.0)
+        sxy = ndimage.gaussian_filter(ix * iy, 2.0)
+        r = sxx * syy - sxy * sxy - 0.04 * (sxx + syy) ** 2
+        # keep away from black (padding) regions: every pixel of the patch must be content
+        content = ndimage.minimum_filter((g8 > 0).astype(np.uint8), size=2 * m + 1)
+        r[content == 0] = 0
+        r[:m] = 0
+        r[-m:] = 0
+        r[:, :m] = 0
+        r[:, -m:] = 0
+        peak = (r == ndimage.maximum_filter(r, size=self.nms)) & (r > 1e-6 * max(float(r.max()), 1e-30))
+        ys, xs = np.nonzero(peak)
+        if len(xs) == 0:
+            return [], None
+        resp = r[ys, xs]
+        order = np.argsort(-resp, kind="stable")[: self.nfeatures]
+        ys, xs, resp = ys[order], xs[order], resp[order]
+        p = self.pairs
+        a = g[ys[:, None] + p[None, :, 1], xs[:, None] + p[None, :, 0]]
+        b = g[ys[:, None] + p[None, :, 3], xs[:, None] + p[None, :, 2]]
+        des = np.packbits(a < b, axis=1)
+        kps = [KeyPoint(x, y, v) for x, y, v in zip(xs, ys, resp)]
+        return kps, des

@@ -210,6 +210,21 @@ def knn2_l2(q, t, ratio=0.65):
     return idx, dist, counts[0]
 
 
+def ratio_compact(idx, dist, ratio):
+    """filter_matches as device arrays: (good_q, good_t) int32 tensors in query order (one sync to
+    learn the count)."""
+    nq = idx.shape[0]
+    dev = idx.device
+    with torch.cuda.device(dev):
+        gq = torch.empty((max(nq, 1),), dtype=torch.int32, device=dev)
+        gt = torch.empty((max(nq, 1),), dtype=torch.int32, device=dev)
+        cnt = torch.empty((1,), dtype=torch.int32, device=dev)
+        check(_lib.lib().isx_ratio_compact(_ptr(idx), _ptr(dist), nq, float(ratio), _ptr(gq), _ptr(gt), _ptr(cnt),
+                                           _stream()))
+        g = int(cnt.item())
+    return gq[:g], gt[:g]
+
+
 # ---------------------------------------------------------------------------------------------
 # image space
 # ---------------------------------------------------------------------------------------------

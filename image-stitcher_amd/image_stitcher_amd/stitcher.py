@@ -1,0 +1,581 @@
+"""Drop-in host layer: the reference's `Stitcher` / `ArbitraryStitcher` / `ConsecutiveStitcher`
+(reference image_stitcher/stitcher.py) with the same constructor keywords, methods, return contracts and
+state machine, driving the HIP kernels of libisx_hip.so through image_stitcher_amd.ops.
+
+What runs where
+  CPU  feature detection (cv2 or a `detector=` object), cv::RNG subset sampling, union-find, file I/O
+  GPU  kNN-2 + Lowe ratio (+ stable compaction), RANSAC hypotheses/scoring/refinement, bbox, warp,
+       alpha / gradient blend, crop; mosaics stay resident in HBM as DeviceImage
+
+Deliberate differences from the reference:
+  * log_level=0 switches logging off instead of raising AttributeError (stitcher.py:69-70);
+  * dropping empty images does not touch self.filepaths when `images=` was given (stitcher.py:275);
+  * matcher=1 (FLANN, approximate and randomised in cv2) is served by the exact brute-force kernel;
+  * mosaics are returned as DeviceImage (array-like; np.asarray() downloads) unless resident=False.
+"""
+import copy
+import logging
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .detect import make_detector
+from .device_image import DeviceImage
+from .pairs import components_from_counts, directed_items, gather_counts, shard_pairs, unordered_pairs
+from .utils.logger import LogWrapper
+from .utils.proc import (crop_image, get_corners_from_image, get_padded_images, get_roi_from_corners,  # noqa: F401
+                         load_image, resize_image, seamless_gradient_merge, seamless_merge,
+                         transform_keypoints_from_roi)
+from .utils.structs import ConstantLengthList, DynamicConnectivity, LazyList  # noqa: F401
+from .utils.utils import no_tqdm, timer, tqdm
+
+
+class TransformDetails:
+    """reference stitcher.py:23-33"""
+
+    def __init__(self, M, src_pts, dst_pts):
+        self.M = M
+        self.src_pts = src_pts
+        self.dst_pts = dst_pts
+
+    def get(self):
+        return self.M, self.src_pts, self.dst_pts
+
+    def __str__(self):
+        return f"M: {self.M}, src_pts: {self.src_pts}, dst_pts: {self.dst_pts}"
+
+
+class DMatch:
+    """cv2.DMatch look-alike, materialised only when user code iterates over matches."""
+    __slots__ = ("queryIdx", "trainIdx", "imgIdx", "distance")
+
+    def __init__(self, q, t, d):
+        self.queryIdx, self.trainIdx, self.imgIdx, self.distance = int(q), int(t), 0, float(d)
+
+
+class KnnMatches:
+    """Result of get_matches: device-resident SoA (idx (nq,2) int32, dist (nq,2) float32).  Iterating
+    yields the reference's list-of-lists of DMatch (rows have min(2, nt) entries)."""
+
+    def __init__(self, idx, dist, count):
+        self.idx, self.dist, self.count = idx, dist, count
+
+    def __len__(self):
+        return self.idx.shape[0]
+
+    def __iter__(self):
+        idx, dist = self.idx.cpu().numpy(), self.dist.cpu().numpy()
+        for q in range(len(idx)):
+            yield [DMatch(q, idx[q, k], dist[q, k]) for k in range(2) if idx[q, k] >= 0]
+
+
+class GoodMatches:
+    """Result of filter_matches: query/train indices (host int32 arrays) in query order."""
+
+    def __init__(self, good_q, good_t, dist=None):
+        self.good_q, self.good_t, self.dist = good_q, good_t, dist
+
+    def __len__(self):
+        return len(self.good_q)
+
+    def __iter__(self):
+        for i in range(len(self.good_q)):
+            d = float(self.dist[i]) if self.dist is not None else float("nan")
+            yield [DMatch(self.good_q[i], self.good_t[i], d)]
+
+
+def _kp_array(kps):
+    """keypoints (cv2.KeyPoint-like objects or an (n,2) array) -> (n,2) float32"""
+    if isinstance(kps, np.ndarray):
+        return kps.astype(np.float32, copy=False).reshape(-1, 2)
+    return np.array([kp.pt for kp in kps], dtype=np.float32).reshape(-1, 2)
+
+
+class Stitcher:
+    def __init__(self,
+                 log_level=2,
+                 output_dir="stitches/",
+                 min_match_count=5,
+                 lowes_ratio_threshold=0.65,
+                 algorithm=0,
+                 matcher=0,
+                 type=0,
+                 resize=None,
+                 consecutive_range=None,
+                 blend_processor=lambda x: x,
+                 blender=1,
+                 ref_image_contrib=0.5,  # Used in alpha blending
+                 *, detector=None, device=None, resident=True):
+        options = {
+            "log_level": [logging.DEBUG, logging.INFO, logging.WARNING],
+            "algorithm": ["sift", "orb", "akaze"],
+            "matcher": ["bf", "flann"],
+            "blender": ["alpha", "gradient"],
+            "type": ["affine", "perspective"],
+        }
+        _logger = logging.getLogger("root")
+        logging.basicConfig(format="[%(filename)s:%(lineno)s - %(funcName)s] %(message)s")
+        self.logger = LogWrapper(_logger)
+        if log_level != 0:
+            self.log_level = options["log_level"][log_level - 1]
+            self.logger.logger.setLevel(self.log_level)
+        else:
+            self.log_level = logging.CRITICAL
+            self.logger.off()
+
+        self.blend_processor = blend_processor
+        self.output_dir = output_dir
+        self.min_match_count = min_match_count
+        self.lowes_ratio_threshold = lowes_ratio_threshold
+        self.ref_image_contrib = ref_image_contrib
+        self.type = type
+        self.resize = resize
+        self.consecutive_range = consecutive_range
+        self.matcher = matcher
+        self.logger.info(f"Initialising {options['matcher'][self.matcher].upper()} matcher")
+        # matcher 0: cv2.BFMatcher() == NORM_L2 for every algorithm (stitcher.py:85); matcher 1 (FLANN) is
+        # approximate in cv2 -- both are served by the exact GPU brute-force L2 kernel.
+        self.matcher_obj = None
+        self.algorithm = algorithm
+        self.logger.info(f"Initialising {options['algorithm'][self.algorithm].upper()} algorithm")
+        self._detector = detector
+        self.logger.info(f"Using {options['type'][self.type].upper()} type stitching")
+        self.blender = blender
+        self.logger.info(f"Using {options['blender'][self.blender].upper()} blender")
+        self.device = torch.device(device) if device is not None else None
+        self.resident = resident
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    @property
+    def algorithm_obj(self):
+        if self._detector is None:
+            self._detector = make_detector(self.algorithm)
+        return self._detector
+
+    def _dev(self):
+        if self.device is None:
+            if not torch.cuda.is_available():
+                raise ops.IsxError("no HIP device: the stitching core has no CPU fallback")
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        return self.device
+
+    # ---- the seven seams (stitcher.py:106-165) -----------------------------------------------------
+    @timer
+    def get_matches(self, descriptors_1, descriptors_2, k=2):
+        if descriptors_1 is None or descriptors_2 is None:
+            return list()
+        if k != 2:
+            raise ops.IsxError("only k=2 is implemented (the reference never asks for another k)")
+        if len(descriptors_1) == 0 or len(descriptors_2) == 0:
+            return list()  # cv2 knnMatch returns [] for an empty query or train set
+        with torch.cuda.device(self._dev()):
+            idx, dist, count = ops.knn2_l2(descriptors_1, descriptors_2, self.lowes_ratio_threshold)
+        return KnnMatches(idx, dist, count)
+
+    @timer
+    def filter_matches(self, matches):
+        if isinstance(matches, KnnMatches):
+            gq, gt = ops.ratio_compact(matches.idx, matches.dist, self.lowes_ratio_threshold)
+            gq_h = gq.cpu().numpy()
+            return GoodMatches(gq_h, gt.cpu().numpy())
+        good = list()  # user-supplied list of DMatch rows: the reference's loop verbatim in behaviour
+        for match in matches:
+            if len(match) > 1:
+                if match[0].distance < self.lowes_ratio_threshold * match[1].distance:
+                    good.append([match[0]])
+            else:
+                good.append([match[0]])
+        return good
+
+    @timer
+    def get_pts(self, src_kp, dst_kp, good_matches):
+        if isinstance(good_matches, GoodMatches):
+            src = _kp_array(src_kp)[good_matches.good_q]
+            dst = _kp_array(dst_kp)[good_matches.good_t]
+        else:
+            src = np.float32([src_kp[m[0].queryIdx].pt for m in good_matches])
+            dst = np.float32([dst_kp[m[0].trainIdx].pt for m in good_matches])
+        return src.reshape(-1, 1, 2), dst.reshape(-1, 1, 2)
+
+    @timer
+    def get_transform(self, src_pts, dst_pts):
+        with torch.cuda.device(self._dev()):
+            M, _mask = ops.estimate_transform(src_pts, dst_pts, perspective=(self.type == 1), device=self._dev())
+        return M
+
+    @timer
+    def warp_target(self, img, ref, M):
+        """Full-canvas warp (API compatibility; `stitch` uses the region path below)."""
+        d = DeviceImage.from_any(img, self._dev())
+        with torch.cuda.device(self._dev()):
+            out = ops.warp(d.t, M, self.type == 1, (0, 0, ref.shape[1], ref.shape[0]))
+        return DeviceImage(out)
+
+    @timer
+    def merge(self, warped_image, ref):
+        if self.blender == 0:
+            return seamless_merge(warped_image, ref, self.ref_image_contrib, device=self._dev())
+        return seamless_gradient_merge(warped_image, ref, device=self._dev())
+
+    @timer
+    def detectAndComputeFromCorners(self, image, corners):
+        roi_img = get_roi_from_corners(image, corners[0], corners[1])
+        self.logger.debug(roi_img.shape)
+        keypoints_roi, thisdes = self.algorithm_obj.detectAndCompute(np.ascontiguousarray(roi_img), None)
+        thiskp = transform_keypoints_from_roi(keypoints_roi, corners[0])
+        return thiskp, thisdes
+
+    @timer
+    def save_last_stitch(self, stitch, filename):
+        processed = self.blend_processor(np.asarray(stitch))
+        if not os.path.exists(self.output_dir):
+            os.makedirs(self.output_dir)
+        filepath = os.path.join(self.output_dir, filename)
+        try:
+            import cv2
+            cv2.imwrite(filepath, processed)
+        except ImportError:
+            from PIL import Image
+            a = np.asarray(processed)
+            Image.fromarray(a[..., ::-1] if a.ndim == 3 else a).save(filepath)
+        self.logger.info(f"Saved last stitch to {filepath}")
+
+    # ---- per-pair pipeline (stitcher.py:176-229) ------------------------------------------------------
+    @staticmethod
+    def _host_canvas(img_host, H, W, ox, oy):
+        shape = (H, W) if img_host.ndim == 2 else (H, W, img_host.shape[2])
+        out = np.zeros(shape, np.uint8)
+        out[oy:oy + img_host.shape[0], ox:ox + img_host.shape[1]] = img_host
+        return out
+
+    @staticmethod
+    def _host_region(img, ox, oy, H, W, p1, p2):
+        """get_roi_from_corners on the padded canvas of `img` (pasted at ox, oy) without building the
+        canvas: numpy slice semantics (clipped to the canvas), zeros outside the image."""
+        if isinstance(img, DeviceImage) and img._host is not None:
+            img = img._host  # the frame came from the host: no download needed
+        x0, y0 = max(0, min(W, p1[0])), max(0, min(H, p1[1]))
+        x1, y1 = max(x0, min(W, p2[0])), max(y0, min(H, p2[1]))
+        c = () if img.ndim == 2 else (img.shape[2],)
+        out = np.zeros((y1 - y0, x1 - x0) + c, np.uint8)
+        ix0, iy0 = max(x0, ox), max(y0, oy)
+        ix1, iy1 = min(x1, ox + img.shape[1]), min(y1, oy + img.shape[0])
+        if ix1 > ix0 and iy1 > iy0:
+            src = img[iy0 - oy:iy1 - oy, ix0 - ox:ix1 - ox]
+            out[iy0 - y0:iy1 - y0, ix0 - x0:ix1 - x0] = np.asarray(src)
+        return out
+
+    def _quad_region(self, M, ox, oy, iw, ih, W, H, margin):
+        """Conservative canvas rectangle that contains every non-zero pixel of the warped frame."""
+        pts = np.array([[ox - 1, oy - 1, 1], [ox + iw, oy - 1, 1], [ox + iw, oy + ih, 1], [ox - 1, oy + ih, 1]], np.float64)
+        Mh = np.vstack([M, [0, 0, 1]]) if M.shape[0] == 2 else M
+        q = pts @ Mh.T
+        if not np.all(np.isfinite(q)) or np.any(q[:, 2] <= 1e-9):
+            return 0, 0, W, H
+        xy = q[:, :2] / q[:, 2:3]
+        if not np.all(np.isfinite(xy)) or np.abs(xy).max() > 1e8:
+            return 0, 0, W, H
+        x0 = int(np.floor(xy[:, 0].min())) - 2 - margin
+        y0 = int(np.floor(xy[:, 1].min())) - 2 - margin
+        x1 = int(np.ceil(xy[:, 0].max())) + 3 + margin
+        y1 = int(np.ceil(xy[:, 1].max())) + 3 + margin
+        return max(0, x0), max(0, y0), min(W, x1), min(H, y1)
+
+    @timer
+    def stitch(self, arg_ref, arg_img, tf=None, corners=None):
+        dev = self._dev()
+        img_d = DeviceImage.from_any(arg_img, dev)
+        ref_d = DeviceImage.from_any(arg_ref, dev)
+        ih, iw = img_d.shape[:2]
+        rh, rw = ref_d.shape[:2]
+        C = img_d.channels
+        if ref_d.channels != C or img_d.ndim != ref_d.ndim:
+            raise ValueError("reference and image must have the same number of channels")
+        # get_padded_images (utils/proc.py:295-304): canvas = ref + 2*img per axis, both pasted centred
+        W, H = rw + 2 * iw, rh + 2 * ih
+        rox, roy = iw, ih
+        ox, oy = (rw + iw) // 2, (rh + ih) // 2
+        with torch.cuda.device(dev):
+            bb = ops.bbox_nonzero(img_d.t).cpu().numpy()
+        if bb[4]:
+            current_corners = ((int(bb[0]) + ox, int(bb[1]) + oy), (int(bb[2]) + ox, int(bb[3]) + oy))
+        else:
+            current_corners = False
+            self.logger.warning("Could not get image corners. The input image has no non-black regions.")
+            corners = None
+
+        if tf is None:
+            thisdes = None
+            if corners is not None and self.consecutive_range is not None:
+                try:
+                    cur_roi = self._host_region(img_d, ox, oy, H, W, current_corners[0], current_corners[1])
+                    kps, thisdes = self.algorithm_obj.detectAndCompute(cur_roi, None)
+                    thiskp = transform_keypoints_from_roi(kps, current_corners[0])
+                    ref_roi = self._host_region(ref_d, rox, roy, H, W, corners[0], corners[1])
+                    kps, refdes = self.algorithm_obj.detectAndCompute(ref_roi, None)
+                    refkp = transform_keypoints_from_roi(kps, corners[0])
+                except Exception as e:  # same recovery as stitcher.py:189-191
+                    self.logger.warning("Error in detecting keypoints from corners. Computing on whole image. Exception: ", str(e))
+                    corners = None
+            if corners is None or self.consecutive_range is None or thisdes is None:
+                thiskp, thisdes = self.algorithm_obj.detectAndCompute(self._host_canvas(img_d.numpy(), H, W, ox, oy), None)
+                refkp, refdes = self.algorithm_obj.detectAndCompute(self._host_canvas(ref_d.numpy(), H, W, rox, roy), None)
+
+            if refdes is None:
+                self.logger.warning("Key points not found in ref. Moving to next blend.")
+                return False
+
+            matches = self.get_matches(thisdes, refdes, 2)
+            good_matches = self.filter_matches(matches)
+            if len(good_matches) >= self.min_match_count:
+                self.logger.debug("Enough matches - {}/{}".format(len(good_matches), self.min_match_count))
+                src_pts, dst_pts = self.get_pts(thiskp, refkp, good_matches)
+                M = self.get_transform(src_pts, dst_pts)
+                tf = TransformDetails(M, src_pts, dst_pts)
+            else:
+                self.logger.debug("Cannot blend. Not enough matches found - {}/{}".format(len(good_matches), self.min_match_count))
+                return None
+        else:
+            M, src_pts, dst_pts = tf.get()
+        if M is None:
+            # the reference passes None to cv2.warp* here, which raises (stitcher.py:208, :216)
+            raise RuntimeError("transform estimation failed (cv2 would raise on M=None)")
+        M = np.asarray(M, np.float64)
+
+        with torch.cuda.device(dev):
+            # warped frame, only where it can be non-zero (+52 px so that the gradient ROI fits)
+            qx0, qy0, qx1, qy1 = self._quad_region(M, ox, oy, iw, ih, W, H, 52)
+            qw, qh = max(0, qx1 - qx0), max(0, qy1 - qy0)
+            shape_c = (C,) if img_d.ndim == 3 else ()
+            wbuf = torch.empty((qh, qw) + shape_c, dtype=torch.uint8, device=dev)
+            wbb = ops.new_bbox(dev)
+            ops.warp(img_d.t, M, self.type == 1, (qx0, qy0, qw, qh), src_xy=(ox, oy), out=wbuf, bbox=wbb)
+            wbb_h = wbb.cpu().numpy()
+            wcorners = ops.bbox_to_corners(wbb_h)
+
+            # merged canvas restricted to U = bounding rectangle of (ref, warped region)
+            ux0, uy0 = min(rox, qx0) if qw and qh else rox, min(roy, qy0) if qw and qh else roy
+            ux1, uy1 = max(rox + rw, qx1) if qw and qh else rox + rw, max(roy + rh, qy1) if qw and qh else roy + rh
+            U = torch.zeros((uy1 - uy0, ux1 - ux0) + shape_c, dtype=torch.uint8, device=dev)
+            ops.copy2d(ref_d.t, U[roy - uy0:roy - uy0 + rh, rox - ux0:rox - ux0 + rw])
+            if qw and qh:
+                if self.blender == 0:
+                    uq = U[qy0 - uy0:qy1 - uy0, qx0 - ux0:qx1 - ux0]
+                    ops.alpha_blend(wbuf, uq, self.ref_image_contrib, out=uq)
+                elif wcorners is not False:
+                    # seamless_gradient_merge ROI: bbox(warped) +- 50 clipped to the canvas (proc.py:199-205)
+                    gx0, gy0 = max(0, wcorners[0][0] - 50), max(0, wcorners[0][1] - 50)
+                    gx1, gy1 = min(W, wcorners[1][0] + 50), min(H, wcorners[1][1] + 50)
+                    ops.gradient_blend_roi(wbuf[gy0 - qy0:gy1 - qy0, gx0 - qx0:gx1 - qx0],
+                                           U[gy0 - uy0:gy1 - uy0, gx0 - ux0:gx1 - ux0])
+            mb = ops.bbox_nonzero(U).cpu().numpy()
+
+        if self.consecutive_range is not None:
+            corners = wcorners
+            if corners is False:
+                self.logger.warning("Could not get image corners. The merged image has no non-black regions.")
+                corners = None
+
+        if not mb[4]:
+            return None  # crop_image returned False (stitcher.py:226-227)
+        mosaic = DeviceImage(U[int(mb[1]):int(mb[3]), int(mb[0]):int(mb[2])])
+        if not self.resident:
+            mosaic = np.ascontiguousarray(mosaic.numpy())
+        return mosaic, corners, tf
+
+
+class ArbitraryStitcher(Stitcher):
+    def __init__(self, images=None, filepaths=None, with_tqdm=True, **kwargs):
+        super().__init__(**kwargs)
+        self.filepaths = None
+        if images is not None:
+            self.images = images
+        elif filepaths is not None:
+            self.filepaths = filepaths
+            self.logger.debug("Input filepaths:", filepaths)
+            self.filepaths = [f for f in self.filepaths if f[-4:] == ".png" or f[-4:] == ".jpg"]
+            self.images = LazyList(lambda index: load_image(self.filepaths[index], to_resize=self.resize), len(self.filepaths))
+        else:
+            raise ValueError("No images specified")
+        if with_tqdm is False:
+            self.tqdm = no_tqdm
+        elif with_tqdm is True:
+            self.tqdm = tqdm
+        else:
+            self.tqdm = with_tqdm
+        self.dist_group = None  # torch.distributed group to shard get_collections over (None = default)
+
+    @timer
+    def update_all_keypoints_and_descriptors(self):
+        kp, des, empty = list(), list(), list()
+        for i in range(0, len(self.images)):
+            thiskp, thisdes = self.algorithm_obj.detectAndCompute(np.asarray(self.images[i]), None)
+            if thisdes is None:
+                empty.append(i)
+            kp.append(thiskp)
+            des.append(thisdes)
+        for index in sorted(empty, reverse=True):  # dropping images with no keypoints (stitcher.py:270-275)
+            if isinstance(self.images, LazyList):
+                self.images.length -= 1
+            else:
+                del self.images[index]
+            del kp[index]
+            del des[index]
+            if self.filepaths is not None:
+                del self.filepaths[index]
+        self.kp = kp
+        self.des = des
+
+    def _pair_counts(self, n):
+        """good-match counts of every unordered pair, both directions: (pairs (p,2), counts (p,2) numpy).
+        Sharded over torch.distributed ranks when a process group is initialised."""
+        import torch.distributed as dist
+        dev = self._dev()
+        world = dist.get_world_size(self.dist_group) if dist.is_available() and dist.is_initialized() else 1
+        rank = dist.get_rank(self.dist_group) if world > 1 else 0
+        pairs = unordered_pairs(n, self.consecutive_range)
+        with torch.cuda.device(dev):
+            P = ops.prepare_descriptors(self.des, device=dev)
+            mine = shard_pairs(pairs, rank, world)
+            items = directed_items(mine, P.starts, P.counts)
+            c = ops.knn2_l2_items(P, items, self.lowes_ratio_threshold).view(-1, 2)
+            allc = gather_counts(c, len(pairs), rank, world, self.dist_group)
+            if world > 1:
+                box = [allc.cpu().numpy() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0, group=self.dist_group)
+                counts = box[0]
+            else:
+                counts = allc.cpu().numpy()
+        return pairs, counts
+
+    @timer
+    def get_collections(self):
+        self.logger.info("Calculating collections")
+        n_before = len(self.images)  # the union-find is sized BEFORE empties are dropped (stitcher.py:283)
+        self.update_all_keypoints_and_descriptors()
+        n = len(self.images)
+        if n >= 2:
+            pairs, counts = self._pair_counts(n)
+        else:
+            pairs, counts = np.zeros((0, 2), np.int64), np.zeros((0, 2), np.int32)
+        self.good_counts = (pairs, counts)
+        collections, connections = components_from_counts(n, pairs, counts[:, 0], counts[:, 1],
+                                                          self.min_match_count, n_union_find=n_before)
+        self.logger.debug(collections)
+        self.logger.info(len(collections), "possible blends found")
+        self.connections = connections
+        return collections
+
+    @timer
+    def stitch_collections(self, collections):
+        """Greedy per-component merge (stitcher.py:306-374); writes blend_{i}.png, returns []."""
+        self.logger.info("Stitching images")
+        progress_bar = tqdm(total=len(self.images)) if self.tqdm is not False and self.tqdm is not no_tqdm else None
+        unblended_collections = copy.deepcopy(collections)
+        blended_collections = list()
+        i = 0
+        while i < len(unblended_collections):
+            idxs = copy.deepcopy(unblended_collections[i])
+            if len(idxs) < 1:
+                self.logger.warning("No images found in unblended group. Moving to next blend.")
+                i += 1  # (the reference `continue`s without advancing and would spin forever)
+                continue
+            ref = idxs[0]
+            reference_image = self.images[ref]
+            idxs.remove(ref)
+            key_points_broken = False
+            while len(idxs) != 0:
+                self.logger.debug(idxs)
+                matched_once = False
+                remove_indexes = list()
+                corners = None
+                for k in idxs:
+                    result = self.stitch(reference_image, self.images[k], corners=corners)
+                    if result is False:
+                        unblended_collections.append(idxs[k:])
+                        key_points_broken = True
+                        corners = None
+                        break
+                    elif result is None:
+                        corners = None
+                    else:
+                        reference_image, corners, tf = result
+                        matched_once = True
+                        remove_indexes.append(k)
+                        if progress_bar is not None:
+                            progress_bar.update(1)
+                for r in remove_indexes:
+                    idxs.remove(r)
+                if matched_once is False or key_points_broken is True:
+                    break
+            self.save_last_stitch(reference_image, f"blend_{i}.png")
+            if progress_bar is not None:
+                progress_bar.update(1)
+            i += 1
+        if progress_bar is not None:
+            progress_bar.close()
+        return blended_collections
+
+
+class ConsecutiveStitcher(Stitcher):
+    def __init__(self,
+                 ref_image_contrib=0.2,
+                 consecutive_range=1,
+                 backup_interval=False,
+                 consecutive_volatility_threshold=4,
+                 **kwargs):
+        super().__init__(**kwargs)
+        self.consecutive_volatility_threshold = consecutive_volatility_threshold
+        self.ref_image_contrib = ref_image_contrib
+        self.stitch_count = 0
+        self.consecutive_range = consecutive_range
+        self.refs = ConstantLengthList(self.consecutive_range)
+        self.refs.append(None)
+        self.corners = None
+        self.image_count = 0
+        self.current_image_count = 0
+        self.backup_interval = backup_interval
+
+    def save_last_stitch(self):
+        return super().save_last_stitch(self.refs[-1], f"blend_{self.stitch_count}.png")
+
+    def save_and_reset(self):
+        self.save_last_stitch()
+        self.refs.append(None)
+        self.stitch_count += 1
+        self.corners = None
+        self.current_image_count = 0
+
+    def finalise_current_image(self, result):
+        self.refs[-1], self.corners, tf = result
+        self.image_count += 1
+        self.current_image_count += 1
+        if self.backup_interval is not False:
+            if self.image_count % self.backup_interval == 0:
+                self.save_last_stitch()
+        return tf
+
+    @timer
+    def stitch_consecutive(self, input_image, tf=None):
+        """stitcher.py:416-439: returns the TransformDetails on success, the caller's `tf` otherwise."""
+        self.logger.info(f"Stitch {self.stitch_count + 1}: Stitching image {self.image_count}")
+        image = resize_image(input_image, self.resize)
+        if self.refs[-1] is None:
+            self.refs[-1] = image
+        else:
+            result = self.stitch(self.refs[-1], image, corners=self.corners, tf=tf)
+            if result is False or result is None:
+                if self.current_image_count < self.consecutive_volatility_threshold:
+                    for exref in reversed(self.refs[:-1]):
+                        result = self.stitch(exref, image, corners=self.corners, tf=tf)
+                        if not (result is False or result is None):
+                            self.refs.pop()
+                            tf = self.finalise_current_image(result)
+                            return tf
+                self.save_and_reset()
+            else:
+                tf = self.finalise_current_image(result)
+                return tf
+        return tf

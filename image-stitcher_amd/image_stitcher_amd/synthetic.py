@@ -60,3 +60,65 @@ def orb_like_descriptors(seed=1235, n_images=8, kp=500, d=32, flips=8, overlap=0
         out.append(cur)
         prev = cur
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# image-level streams
+# ---------------------------------------------------------------------------------------------
+def procedural_world(seed=42, h=3072, w=6144, channels=3):
+    """Seeded texture: multi-octave value noise + random rectangles, uint8 BGR, every pixel >= 12 so
+    content is never "black" under the reference's gray > 10 / gray != 0 tests."""
+    from scipy import ndimage
+    rng = np.random.Generator(np.random.PCG64(seed))
+    acc = np.zeros((h, w, channels), np.float32)
+    amp = 1.0
+    for cell in (256, 96, 32, 12, 5):
+        gh, gw = h // cell + 3, w // cell + 3
+        g = rng.random((gh, gw, channels), dtype=np.float32)
+        up = ndimage.zoom(g, (cell, cell, 1), order=1)[:h, :w]
+        acc += amp * up
+        amp *= 0.62
+    acc = (acc - acc.min()) / (acc.max() - acc.min())
+    img = 30 + 200 * acc
+    for _ in range(int(h * w / 40000)):
+        y, x = rng.integers(0, h - 8), rng.integers(0, w - 8)
+        hh, ww = rng.integers(4, 60, 2)
+        img[y:y + hh, x:x + ww] = rng.integers(12, 256, channels)
+    img = np.clip(img, 12, 255).astype(np.uint8)
+    return img if channels > 1 else img[..., 0]
+
+
+def crop_path(world, n_frames, frame_hw=(480, 640), step_frac=0.15, max_rot_deg=1.0, seed=43, start=None):
+    """Frames along a mostly-horizontal path: `step_frac` of the frame width per frame plus a small
+    vertical drift and a rotation in [-max_rot, max_rot] degrees.  Returns (frames list of uint8
+    arrays, poses list of (cx, cy, theta_rad))."""
+    from scipy import ndimage
+    rng = np.random.Generator(np.random.PCG64(seed))
+    fh, fw = frame_hw
+    H, W = world.shape[:2]
+    cx = fw * 0.75 if start is None else start[0]
+    cy = H / 2 if start is None else start[1]
+    frames, poses = [], []
+    ys, xs = np.mgrid[0:fh, 0:fw].astype(np.float32)
+    xs -= (fw - 1) / 2
+    ys -= (fh - 1) / 2
+    for k in range(n_frames):
+        th = np.deg2rad(rng.uniform(-max_rot_deg, max_rot_deg)) if max_rot_deg > 0 else 0.0
+        c, s = np.cos(th), np.sin(th)
+        wx = cx + c * xs - s * ys
+        wy = cy + s * xs + c * ys
+        if max_rot_deg == 0 and float(cx).is_integer() and float(cy).is_integer() and fw % 2 == 0 and fh % 2 == 0:
+            pass
+        chans = []
+        wv = world.reshape(H, W, -1)
+        for ch in range(wv.shape[2]):
+            chans.append(ndimage.map_coordinates(wv[..., ch], [wy, wx], order=1, mode="nearest"))
+        f = np.stack(chans, -1).astype(np.uint8)
+        frames.append(np.ascontiguousarray(f if world.ndim == 3 else f[..., 0]))
+        poses.append((cx, cy, th))
+        cx += step_frac * fw
+        cy += rng.uniform(-0.03, 0.03) * fh
+        cy = min(max(cy, fh * 0.8), H - fh * 0.8)
+        if cx > W - fw * 0.75:
+            break
+    return frames, poses

@@ -88,6 +88,12 @@ int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_dev, const i
                       int32_t *idx_out_dev, float *dist_out_dev, const int64_t *out_start_dev,
                       int32_t *count_out_dev, void *stream);
 
+/* Stitcher.filter_matches as a list (stitcher.py:118-127): stable compaction, in query order, of the rows
+ * of a kNN-2 result that pass the ratio test (single-match rows are kept unconditionally, :125-126).
+ * good_q/good_t: nq int32 each (capacity); count_out_dev: 1 int32 = len(good_matches). */
+int isx_ratio_compact(const int32_t *idx_dev, const float *dist_dev, int nq, double ratio,
+                      int32_t *good_q_out_dev, int32_t *good_t_out_dev, int32_t *count_out_dev, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Image space.  All images: uint8, interleaved channels (c = 1 or 3), PITCHED: `pitch` is the row
  * stride in bytes, so a crop / ROI of a device image is a pointer to its first pixel + the parent pitch.

@@ -1,0 +1,145 @@
+"""End-to-end GPU tests of the drop-in host layer (ConsecutiveStitcher / ArbitraryStitcher) against the
+reference pipeline restated on the CPU oracle (tests/oracle_stitch.py).  Detection uses the same
+deterministic numpy detector on both sides, so both paths see identical descriptors."""
+import numpy as np
+import pytest
+
+from oracle_stitch import Cfg, oracle_stitch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world():
+    from image_stitcher_amd.synthetic import procedural_world
+    return procedural_world(seed=42, h=800, w=2200)
+
+
+def _frames(world, n, hw=(240, 320), seed=1, rot=1.0):
+    from image_stitcher_amd.synthetic import crop_path
+    return crop_path(world, n, hw, seed=seed, max_rot_deg=rot)[0]
+
+
+def _apply(M, p):
+    M = np.vstack([M, [0, 0, 1]]) if M.shape[0] == 2 else M
+    q = np.c_[p, np.ones(len(p))] @ M.T
+    return q[:, :2] / q[:, 2:3]
+
+
+@pytest.mark.parametrize("type_,blender,contrib", [(0, 1, 0.2), (1, 0, 0.5), (0, 0, 0.2), (1, 1, 0.2)])
+def test_consecutive_stream_matches_oracle_frame_by_frame(cuda, orc, world, tmp_path, type_, blender, contrib):
+    from image_stitcher_amd import ConsecutiveStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    frames = _frames(world, 6)
+    det = NumpyOrbLite(nfeatures=600)
+    st = ConsecutiveStitcher(log_level=3, output_dir=str(tmp_path), type=type_, blender=blender,
+                             ref_image_contrib=contrib, consecutive_range=1, algorithm=1, detector=det)
+    cfg = Cfg(type=type_, blender=blender, ref_image_contrib=contrib, consecutive_range=1)
+    assert st.stitch_consecutive(frames[0]) is None and st.refs[-1] is frames[0]
+    for k, f in enumerate(frames[1:]):
+        ref_before = np.array(np.asarray(st.refs[-1]))
+        corners_before = st.corners
+        tf = st.stitch_consecutive(f)
+        assert tf is not None, f"frame {k + 1} failed to stitch"
+        got = np.asarray(st.refs[-1])
+        # (a) the oracle's own run from the same inputs: identical good matches / points, M within tolerance
+        o = oracle_stitch(ref_before, f, det, cfg, corners=corners_before)
+        assert o not in (None, False)
+        oM, osrc, odst = o[2]
+        assert np.array_equal(tf.src_pts, osrc) and np.array_equal(tf.dst_pts, odst)
+        assert tf.src_pts.dtype == np.float32 and tf.src_pts.shape[1:] == (1, 2)
+        rms = np.sqrt(((_apply(tf.M, osrc.reshape(-1, 2).astype(np.float64)) - _apply(oM, osrc.reshape(-1, 2).astype(np.float64))) ** 2).sum(1).mean())
+        assert rms < 1e-3  # gate: 0.5 px
+        # (b) warp + blend + bbox + crop fed the SAME transform: bit exact mosaic and corners
+        o2 = oracle_stitch(ref_before, f, det, cfg, tf=(tf.M, tf.src_pts, tf.dst_pts), corners=corners_before)
+        assert got.shape == o2[0].shape
+        assert np.array_equal(got, o2[0]), f"{(got != o2[0]).sum()} pixels differ"
+        assert st.corners == o2[1]
+    assert st.image_count == 5 and st.current_image_count == 5 and st.stitch_count == 0
+    assert got.shape[1] > frames[0].shape[1] * 1.5  # the mosaic really grew
+
+
+def test_rgb_plus_depth_reusing_tf(cuda, orc, world, tmp_path):
+    """BASELINE config 4 (README 'synchronised stitching'): the depth stitcher reuses the RGB transform
+    (warp/blend-only path, blender=0, ref_image_contrib=0.5); uint16 depth wraps to uint8 exactly as the
+    reference's pad_image does (utils/proc.py:283-291)."""
+    from image_stitcher_amd import ConsecutiveStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    frames = _frames(world, 4)
+    rng = np.random.default_rng(0)
+    depth = [(np.linspace(300, 3000, f.shape[1])[None, :] + 40 * k + rng.integers(0, 3, f.shape[:2])).astype(np.uint16)
+             for k, f in enumerate(frames)]
+    det = NumpyOrbLite(nfeatures=600)
+    kw = dict(log_level=3, output_dir=str(tmp_path), type=0, blender=0, ref_image_contrib=0.5, consecutive_range=1)
+    rgb = ConsecutiveStitcher(algorithm=1, detector=det, **kw)
+    dep = ConsecutiveStitcher(algorithm=1, detector=det, **kw)
+    cfg = Cfg(type=0, blender=0, ref_image_contrib=0.5, consecutive_range=1)
+    for k in range(len(frames)):
+        dref = None if dep.refs[-1] is None else np.array(np.asarray(dep.refs[-1])).astype(np.uint8)
+        tf = rgb.stitch_consecutive(frames[k])
+        tf2 = dep.stitch_consecutive(depth[k], tf)
+        if k == 0:
+            assert tf is None and tf2 is None
+            continue
+        assert tf2 is tf
+        o = oracle_stitch(dref, depth[k].astype(np.uint8), det, cfg, tf=(tf.M, tf.src_pts, tf.dst_pts))
+        assert np.array_equal(np.asarray(dep.refs[-1]), o[0])
+
+
+def test_failed_frame_resets_the_mosaic(cuda, world, tmp_path):
+    """stitcher.py:425-433: a frame that cannot be matched saves blend_N.png, starts a new mosaic and is
+    itself dropped; the caller's tf (None) comes back."""
+    from image_stitcher_amd import ConsecutiveStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    frames = _frames(world, 3)
+    from image_stitcher_amd.synthetic import procedural_world
+    other = procedural_world(seed=99, h=240, w=320)  # unrelated content: no overlap
+    st = ConsecutiveStitcher(log_level=3, output_dir=str(tmp_path), consecutive_range=2, algorithm=1,
+                             min_match_count=40, detector=NumpyOrbLite(nfeatures=400),
+                             consecutive_volatility_threshold=0)
+    st.stitch_consecutive(frames[0])
+    assert st.stitch_consecutive(frames[1]) is not None
+    assert st.stitch_consecutive(other) is None
+    assert st.stitch_count == 1 and st.refs[-1] is None and st.corners is None and st.current_image_count == 0
+    assert (tmp_path / "blend_0.png").exists()
+    assert len(st.refs) == 2 and st.refs[0] is not None  # the ring keeps the old mosaic
+    st.stitch_consecutive(frames[2])
+    assert st.refs[-1] is frames[2]  # first frame of the new mosaic, no work
+
+
+def test_get_collections_small(cuda, orc, world):
+    """ArbitraryStitcher.get_collections (stitcher.py:280-304) incl. the phantom-singleton quirk."""
+    from image_stitcher_amd import ArbitraryStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    a = _frames(world, 4, seed=3)
+    from image_stitcher_amd.synthetic import crop_path
+    b = crop_path(world, 3, (240, 320), seed=5, start=(1500.0, 400.0))[0]  # far from the a-chain: no overlap
+    black = np.zeros_like(a[0])
+    order = [a[0], b[0], a[1], black, b[1], a[2], b[2], a[3]]
+    det = NumpyOrbLite(nfeatures=500)
+    st = ArbitraryStitcher(images=list(order), with_tqdm=False, log_level=3, algorithm=1, detector=det,
+                           min_match_count=15)
+    cols = st.get_collections()
+    # oracle: same loop on the CPU
+    des = [det.detectAndCompute(im)[1] for im in order]
+    keep = [i for i, d in enumerate(des) if d is not None]
+    des = [des[i] for i in keep]
+    n = len(des)
+    from image_stitcher_amd.utils.structs import DynamicConnectivity
+    dc = DynamicConnectivity(len(order))
+    for i in range(n):
+        for j in range(n):
+            if i != j and orc.match_count(des[i], des[j], 0.65) >= 15:
+                dc.union(i, j)
+    exp = sorted(dc.get_connected_components(), key=len, reverse=True)
+    assert cols == exp
+    assert [len(c) for c in cols] == [4, 3, 1]  # a-chain, b-chain, phantom trailing singleton (index 7)
+    assert len(st.des) == 7 and len(st.images) == 7
+
+
+def test_no_gpu_free_cpu_path(cuda):
+    """The product never falls back to the CPU: CPU tensors are rejected loudly."""
+    import torch
+    from image_stitcher_amd import ops
+    with pytest.raises(ops.IsxError):
+        ops.bbox_nonzero(torch.zeros((4, 4), dtype=torch.uint8))
