@@ -150,7 +150,7 @@ __device__ __forceinline__ bool cand_better(const Cand a, const Cand b) {
 }
 
 template <int KS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 knn2_l2_kernel(const int8_t *__restrict__ desc, const uint32_t *__restrict__ cbase,
                const int32_t *__restrict__ nrm, const isx_knn_item *__restrict__ items, int n_items,
                int nqb, double ratio, int32_t *__restrict__ idx_out, float *__restrict__ dist_out,
@@ -345,6 +345,10 @@ extern "C" int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_d
     ISX_REQUIRE((idx_out_dev == nullptr) == (dist_out_dev == nullptr), "idx_out and dist_out must be given together");
     ISX_REQUIRE(idx_out_dev == nullptr || out_start_dev != nullptr, "out_start_dev is required with idx/dist outputs");
     if (n_items == 0 || max_nq == 0) return ISX_OK;
+    if (idx_out_dev == nullptr) {
+        ISX_REQUIRE(count_out_dev, "nothing to compute: idx/dist and count outputs are all NULL");
+        return isx_knn2_l2_count_items(desc_dev, nrm_dev, d_pad, items_dev, n_items, max_nq, ratio, count_out_dev, 0, stream);
+    }
     ISX_REQUIRE(desc_dev && cbase_dev && nrm_dev && items_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
     const int nqb = (max_nq + 255) / 256;
@@ -359,6 +363,284 @@ extern "C" int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_d
     else
         hipLaunchKernelGGL((knn2_l2_kernel<1>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
     return isx_launch_status("knn2_l2_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Count-only kNN-2 + ratio kernel: the loop body of ArbitraryStitcher.get_collections
+// (reference stitcher.py:292-296 needs only len(good_matches) per ordered pair).
+//
+// 1.25 VALU ops per distance, no train indices.  The MFMA chain starts from C = cin_j = B2 - ceil(nb'_j/2),
+// so the accumulator IS the ranking value
+//       h_j = a'.b'_j - ceil(nb'_j/2) + B2 > 0,      2 a'.b'_j - nb'_j = 2 (h_j - B2) + p_j,  p_j = nb'_j & 1
+// A lane owns one query and sees its train rows in 8 streams (accumulator registers r and r+8).  Two
+// values (x, y) are folded at a time with three-input ops:
+//       t    = med3(m[r], x[r], y[r])      second largest of {stream max so far, x, y}
+//       m[r] = max3(m[r], x[r], y[r])      stream maximum
+//       G    = max3(G, t[r], t[r'])        largest runner-up seen in ANY stream
+// The runner-up of a stream never exceeds its maximum, so at the end
+//       H1 = max_r m[r],   H2 = max(second largest of {m[r]}, G)
+// are exactly the two largest h of the query.  The unknown parity bits p leave each squared distance
+// known to within {s-1, s}; the ratio test is monotone in both, so it is evaluated at the two extreme
+// corners and only if they disagree (~1e-4 of the queries) the wave recomputes that query exactly
+// (v_dot4 over every train row).  The count is bit-identical to the index kernel's and the oracle's.
+// ------------------------------------------------------------------------------------------------
+#define ISX_B2 4194304 /* 1 << 22: keeps h in [2^20, 2^23) for every valid row; 0 = absent */
+
+__device__ __forceinline__ bool ratio_good(int s0, int s1, double ratio) {
+    return (double)sqrtf((float)s0) < ratio * (double)sqrtf((float)s1);
+}
+
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c) {
+    const unsigned ab = a > b ? a : b;
+    return ab > c ? ab : c;
+}
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+    const unsigned lo = a < b ? a : b, hi = a < b ? b : a;
+    const unsigned t = hi < c ? hi : c;
+    return lo > t ? lo : t;
+}
+
+// Exact two largest values 2a'.b'-nb' of one query over all nt train rows, computed by the whole wave
+// (INT32_MIN = absent).
+template <int DP>
+__device__ __noinline__ void knn2_exact_scan(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm,
+                                             int q_row, int t_start, int nt, int lane, int &v1, int &v2) {
+    const int *qp = (const int *)(desc + (int64_t)q_row * DP);
+    v1 = INT32_MIN;
+    v2 = INT32_MIN;
+    for (int j = lane; j < nt; j += 64) {
+        const int *tp = (const int *)(desc + (int64_t)(t_start + j) * DP);
+        int dot = 0;
+#pragma unroll 8
+        for (int w = 0; w < DP / 4; w++) dot = __builtin_amdgcn_sdot4(qp[w], tp[w], dot, false);
+        const int v = 2 * dot - nrm[t_start + j];
+        if (v > v1) {
+            v2 = v1;
+            v1 = v;
+        } else if (v > v2) {
+            v2 = v;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int o1 = __shfl_xor(v1, m), o2 = __shfl_xor(v2, m);
+        const int hi = v1 > o1 ? v1 : o1, lo = v1 > o1 ? o1 : v1;
+        const int s = v2 > o2 ? v2 : o2;
+        v1 = hi;
+        v2 = lo > s ? lo : s;
+    }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256, 2)
+knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm,
+                  const isx_knn_item *__restrict__ items, int n_items, int nqb, double ratio,
+                  int32_t *__restrict__ count_out, int flags) {
+    constexpr int DP = 32 * KS;
+    constexpr int SLOTS = 2 * KS;
+    constexpr int SH = (KS == 4) ? 1 : (KS == 2) ? 2 : 3;
+    constexpr int CHUNK = 128;
+    constexpr int BUF = CHUNK * DP + CHUNK * 4;
+    __shared__ __align__(16) unsigned char smem[2 * BUF];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int k = id >> 3;
+    const int qb = k % nqb;
+    const int item_i = (k / nqb) * 8 + xcd;
+    if (item_i >= n_items) return;
+    const isx_knn_item it = items[item_i];
+    if (qb * 256 >= it.nq) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, col = lane & 31;
+    const int q0 = qb * 256 + wave * 64;
+    const int nt = it.nt;
+    const bool wave_live = q0 < it.nq;
+
+    v4i qf[2][KS];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        const int qi = q0 + cb * 32 + col;
+        const v4i *p = (const v4i *)(desc + (int64_t)(it.q_start + (qi < it.nq ? qi : 0)) * DP);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) qf[cb][ks] = (qi < it.nq) ? p[2 * ks + h] : v4i{0, 0, 0, 0};
+    }
+
+unsigned m[2][8], G[2] = {0u, 0u};
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++)
+#pragma unroll
+        for (int r = 0; r < 8; r++) m[cb][r] = 0u;
+
+    const int n_chunks = (nt + CHUNK - 1) / CHUNK;
+    v4i st[KS];
+    unsigned st_cin = 0;
+
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < KS; i++) {
+            const int u = tid + 256 * i;
+            const int row = u / SLOTS, slot = u % SLOTS;
+            const int jl = c * CHUNK + row;
+            st[i] = (jl < nt) ? *(const v4i *)(desc + (int64_t)(it.t_start + jl) * DP + slot * 16)
+                              : v4i{0, 0, 0, 0};
+        }
+        if (tid < CHUNK) {
+            const int jl = c * CHUNK + tid;
+            st_cin = (jl < nt) ? (unsigned)(ISX_B2 - ((nrm[it.t_start + jl] + 1) >> 1)) : 0u;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        unsigned char *base = smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < KS; i++) {
+            const int u = tid + 256 * i;
+            const int row = u / SLOTS, slot = u % SLOTS;
+            *(v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4)) = st[i];
+        }
+        if (tid < CHUNK) *(unsigned *)(base + CHUNK * DP + tid * 4) = st_cin;
+    };
+    // one 32-row tile against both query column blocks
+    auto mfma_tile = [&](const unsigned char *base, int tl, v16i (&acc)[2]) {
+        const int row = tl * 32 + col;
+        v4i a[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int slot = 2 * ks + h;
+            a[ks] = *(const v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4));
+        }
+        v4i cv[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) cv[g] = *(const v4i *)(base + CHUNK * DP + (tl * 32 + 8 * g + 4 * h) * 4);
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+            v16i ac = {cv[0][0], cv[0][1], cv[0][2], cv[0][3], cv[1][0], cv[1][1], cv[1][2], cv[1][3],
+                       cv[2][0], cv[2][1], cv[2][2], cv[2][3], cv[3][0], cv[3][1], cv[3][2], cv[3][3]};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], qf[cb][ks], ac, 0, 0, 0);
+            acc[cb] = ac;
+        }
+    };
+    // fold one tile into the running stream maxima / runner-up (20 VALU ops per column block)
+    auto fold_tile = [&](const v16i (&acc)[2]) {
+#pragma unroll
+        for (int cb = 0; cb < 2; cb++) {
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+                unsigned x0 = (unsigned)acc[cb][r], y0 = (unsigned)acc[cb][r + 8];
+                unsigned x1 = (unsigned)acc[cb][r + 1], y1 = (unsigned)acc[cb][r + 9];
+                const unsigned t0 = umed3(m[cb][r], x0, y0);
+                const unsigned t1 = umed3(m[cb][r + 1], x1, y1);
+                // opaque re-definitions: keep the optimiser from sharing max(m, x) between the med3 and
+                // the max3 (which would split the max3 into two v_max_u32); they emit no instruction
+                asm("" : "+v"(x0));
+                asm("" : "+v"(x1));
+                m[cb][r] = umax3(x0, y0, m[cb][r]);
+                m[cb][r + 1] = umax3(x1, y1, m[cb][r + 1]);
+                G[cb] = umax3(t0, t1, G[cb]);
+            }
+        }
+    };
+
+    if (n_chunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+
+    // software pipeline: the MFMAs of tile t+1 are issued before the fold of tile t, so that matrix and
+    // vector work of ONE wave overlap; accB is carried across the chunk boundary (zeros = absent rows)
+    v16i accA[2], accB[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) accB[cb] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < n_chunks && !(flags & 256)) load_chunk(c + 1);
+        const unsigned char *base = smem + buf * BUF;
+        if (wave_live) {
+            mfma_tile(base, 0, accA);
+            fold_tile(accB);
+            mfma_tile(base, 1, accB);
+            fold_tile(accA);
+            mfma_tile(base, 2, accA);
+            fold_tile(accB);
+            mfma_tile(base, 3, accB);
+            fold_tile(accA);
+        }
+        if (c + 1 < n_chunks && !(flags & 512)) store_chunk(buf ^ 1);
+        if (!(flags & 1024)) __syncthreads();
+    }
+    if (!wave_live) return;
+    fold_tile(accB);
+
+    int good_cnt = 0;
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+        // two largest h of this lane's half of the train rows, then of the lane pair (col, 0|1)
+        unsigned b1 = 0u, b2 = 0u;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const unsigned v = m[cb][r];
+            b2 = umed3(b1, b2, v); // b1 >= b2 throughout
+            b1 = b1 > v ? b1 : v;
+        }
+        b2 = b2 > G[cb] ? b2 : G[cb]; // a stream's runner-up never exceeds b1
+        const unsigned o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+        const unsigned H1 = b1 > o1 ? b1 : o1;
+        const unsigned mn = b1 > o1 ? o1 : b1, mx2 = b2 > o2 ? b2 : o2;
+        const unsigned H2 = mn > mx2 ? mn : mx2;
+        const int qi = q0 + cb * 32 + col;
+        const bool mine = h == 0 && qi < it.nq;
+        bool good = false, amb = false;
+        int na = 0;
+        if (mine && H1 != 0u) {
+            if (H2 == 0u) {
+                good = true; // single-match row: kept unconditionally (stitcher.py:125-126)
+            } else {
+                na = nrm[it.q_start + qi];
+                const int s0_hi = na - 2 * ((int)H1 - ISX_B2), s1_hi = na - 2 * ((int)H2 - ISX_B2);
+                const int s0_lo = s0_hi > 0 ? s0_hi - 1 : 0, s1_lo = s1_hi > 0 ? s1_hi - 1 : 0;
+                const bool g_best = ratio_good(s0_lo, s1_hi, ratio), g_worst = ratio_good(s0_hi, s1_lo, ratio);
+                good = g_best;
+                amb = (g_best != g_worst) || (flags & 1);
+            }
+        }
+        if (flags & 2048) amb = false;
+        unsigned long long am = __ballot(amb);
+        while (am) {
+            const int L = __ffsll((long long)am) - 1;
+            am &= am - 1;
+            int v1, v2;
+            knn2_exact_scan<DP>(desc, nrm, it.q_start + __shfl(qi, L), it.t_start, nt, lane, v1, v2);
+            const int nal = __shfl(na, L);
+            if (lane == L) good = ratio_good(nal - v1, nal - v2, ratio);
+        }
+        good_cnt += __popcll(__ballot(good));
+    }
+    if (lane == 0 && good_cnt) atomicAdd(&count_out[item_i], good_cnt);
+}
+
+extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, int d_pad,
+                                       const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
+                                       int32_t *count_out_dev, int flags, void *stream) {
+    ISX_REQUIRE(d_pad == 32 || d_pad == 64 || d_pad == 128, "d_pad must be 32, 64 or 128 (got %d)", d_pad);
+    ISX_REQUIRE(n_items >= 0 && max_nq >= 0, "negative size");
+    if (n_items == 0 || max_nq == 0) return ISX_OK;
+    ISX_REQUIRE(desc_dev && nrm_dev && items_dev && count_out_dev, "null device pointer");
+    ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
+    const int nqb = (max_nq + 255) / 256;
+    const int64_t blocks = (int64_t)((n_items + 7) / 8) * 8 * nqb;
+    ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)blocks), block(256);
+    if (d_pad == 128)
+        hipLaunchKernelGGL((knn2_count_kernel<4>), grid, block, 0, st, desc_dev, nrm_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
+    else if (d_pad == 64)
+        hipLaunchKernelGGL((knn2_count_kernel<2>), grid, block, 0, st, desc_dev, nrm_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
+    else
+        hipLaunchKernelGGL((knn2_count_kernel<1>), grid, block, 0, st, desc_dev, nrm_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
+    return isx_launch_status("knn2_count_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------

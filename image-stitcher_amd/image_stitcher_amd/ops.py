@@ -140,13 +140,14 @@ def plan_items(items, device, xcd_order=True):
     return run_items, perm, items_dev, inv_dev, inv_np
 
 
-def knn2_l2_items(P, items, ratio, want_matches=False, xcd_order=True, plan=None, events=None):
+def knn2_l2_items(P, items, ratio, want_matches=False, xcd_order=True, plan=None, events=None, verify_all=False):
     """Run the fused kNN-2 + ratio kernel over directed work items.
 
     items: (n,4) int32 rows (q_start, nq, t_start, nt) into P's row space.
     plan: optional result of plan_items(items) (cached reordering + device copy of the item list).
     events: optional (start, end) torch.cuda.Event pair recorded immediately around the kernel launch
     on the launch stream (what bench.py uses for the per-launch kernel duration).
+    want_matches=False runs the count-only kernel (isx_knn2_l2_count_items).
     Returns counts (n,) int32 device tensor [len(good_matches) per item] and, if want_matches,
     (idx, dist, out_starts): idx/dist are (sum nq, 2) device tensors, out_starts (n,) numpy int64.
     """
@@ -178,9 +179,13 @@ def knn2_l2_items(P, items, ratio, want_matches=False, xcd_order=True, plan=None
             out_dev = torch.from_numpy(out_run[:-1].copy()).to(dev, non_blocking=True)
         if events is not None:
             events[0].record()
-        check(L.isx_knn2_l2_items(_ptr(P.desc), _ptr(P.cbase), _ptr(P.nrm), P.d_pad, _ptr(items_dev), m,
-                                  max_nq, float(ratio), _ptr(idx), _ptr(dist), _ptr(out_dev),
-                                  _ptr(counts), _stream()))
+        if want_matches:
+            check(L.isx_knn2_l2_items(_ptr(P.desc), _ptr(P.cbase), _ptr(P.nrm), P.d_pad, _ptr(items_dev), m,
+                                      max_nq, float(ratio), _ptr(idx), _ptr(dist), _ptr(out_dev),
+                                      _ptr(counts), _stream()))
+        else:  # count-only kernel (verify_all: test-hook flags of isx_knn2_l2_count_items)
+            check(L.isx_knn2_l2_count_items(_ptr(P.desc), _ptr(P.nrm), P.d_pad, _ptr(items_dev), m, max_nq,
+                                            float(ratio), _ptr(counts), int(verify_all), _stream()))
         if events is not None:
             events[1].record()
         if reordered:

@@ -88,6 +88,17 @@ int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_dev, const i
                       int32_t *idx_out_dev, float *dist_out_dev, const int64_t *out_start_dev,
                       int32_t *count_out_dev, void *stream);
 
+/* Count-only form of the above: the loop body of ArbitraryStitcher.get_collections
+ * (stitcher.py:292-296 uses only len(good_matches) of every ordered pair).  Same counts, bit for bit,
+ * as isx_knn2_l2_items; it skips the train indices, which takes a third off the per-distance work.
+ * isx_knn2_l2_items routes here by itself when idx_out_dev is NULL.
+ *   count_out_dev : int32 per item, MUST be zeroed by the caller
+ *   flags         : bit 0 = decide EVERY query by the exact per-query scan (test hook, slow); bits >= 8
+ *                   are timing diagnostics that give WRONG counts (tools/knn_variants.py), keep them 0 */
+int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, int d_pad,
+                            const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
+                            int32_t *count_out_dev, int flags, void *stream);
+
 /* Stitcher.filter_matches as a list (stitcher.py:118-127): stable compaction, in query order, of the rows
  * of a kNN-2 result that pass the ratio test (single-match rows are kept unconditionally, :125-126).
  * good_q/good_t: nq int32 each (capacity); count_out_dev: 1 int32 = len(good_matches). */

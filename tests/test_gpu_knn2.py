@@ -103,3 +103,61 @@ def test_knn2_items_batched_counts(cuda, orc):
         ridx, _ = orc.knn2(lst[i], lst[j])
         assert np.array_equal(idx[starts[e]:starts[e] + len(lst[i])], ridx)
     assert np.array_equal(counts2.cpu().numpy(), ref)
+
+
+# ---- count-only kernel (isx_knn2_l2_count_items): same counts as the index kernel and the oracle ----------
+def _count_case(orc, des_list, ratio, verify_all):
+    import torch
+    from image_stitcher_amd import ops
+    P = ops.prepare_descriptors(des_list)
+    n = len(des_list)
+    items = np.array([(P.starts[i], P.counts[i], P.starts[j], P.counts[j])
+                      for i in range(n) for j in range(n) if i != j and P.counts[i] and P.counts[j]], np.int32)
+    pairs = [(i, j) for i in range(n) for j in range(n) if i != j and P.counts[i] and P.counts[j]]
+    c = ops.knn2_l2_items(P, items, ratio, verify_all=verify_all)
+    c_idx, _ = ops.knn2_l2_items(P, items, ratio, want_matches=True)
+    torch.cuda.synchronize()
+    c, c_idx = c.cpu().numpy(), c_idx.cpu().numpy()
+    exp = np.array([orc.match_count(des_list[i], des_list[j], ratio) for i, j in pairs], np.int32)
+    assert np.array_equal(c_idx, exp)
+    assert np.array_equal(c, exp), f"count kernel differs on {np.nonzero(c != exp)[0][:10]}"
+
+
+@pytest.mark.parametrize("verify_all", [False, 1, 3])
+def test_count_kernel_matches_oracle_sift_like(cuda, orc, verify_all):
+    from image_stitcher_amd.synthetic import overlapping_crops_descriptors
+    des, _ = overlapping_crops_descriptors(seed=11, n_scenes=2, imgs_per_scene=3, kp=700, step=100)
+    _count_case(orc, [d for d in des], 0.65, verify_all)
+
+
+@pytest.mark.parametrize("d,hi", [(128, 180), (61, 256), (32, 256)])
+def test_count_kernel_ragged_and_ties(cuda, orc, d, hi):
+    rng = np.random.default_rng(5 + d)
+    sizes = [1, 2, 33, 257, 700, 129, 64]
+    des = [rng.integers(0, hi, (s, d), dtype=np.uint8) for s in sizes]
+    des[4][10:40] = des[3][5:35]      # planted matches
+    des[4][100] = des[4][101]         # duplicate train rows (ties)
+    des[5][:] = des[5][0]             # all-identical image: every distance ties
+    for ratio in (0.65, 0.9, 1.0):
+        _count_case(orc, des, ratio, False)
+    _count_case(orc, des, 0.65, 1)
+    _count_case(orc, des, 0.65, 3)
+
+
+def test_count_kernel_ratio_boundary_parity_bit(cuda, orc):
+    """Queries whose ratio test sits within one unit of squared distance of the threshold (3k vs 4m
+    below): the count kernel has to take its exact per-query path there and still agree with the oracle."""
+    rng = np.random.default_rng(77)
+    base = rng.integers(100, 140, (128,), dtype=np.uint8)
+    far = rng.integers(0, 60, (200, 128), dtype=np.uint8)
+    q = np.repeat(base[None], 40, 0)
+    for k in range(1, 41):
+        q[k - 1, :k] += 1              # ||q_k - base||^2 = k
+    des = [q]
+    for m in range(1, 32):
+        t = np.concatenate([base[None], base[None], far])
+        t[1, 64:64 + m] += 2           # ||q_k - t1||^2 = k + 4m ; ratio 0.5: good <=> 3k < 4m
+        des.append(t[rng.permutation(len(t))])
+    _count_case(orc, des[:12], 0.5, False)
+    _count_case(orc, [des[0]] + des[12:22], 0.5, False)
+    _count_case(orc, [des[0]] + des[22:], 0.5, False)
