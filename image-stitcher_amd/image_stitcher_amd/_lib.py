@@ -25,6 +25,11 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isx_knn2_l2_count_items": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_void_p, c_int,
                                         c_void_p]),
+    "isx_knn2_hamming_items": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
+    "isx_f32_norms": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
+    "isx_knn2_f32_items": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
     "isx_ratio_compact": (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isx_bbox_nonzero": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "isx_bbox_reset": (c_int, [c_void_p, c_void_p]),

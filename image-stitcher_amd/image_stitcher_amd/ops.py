@@ -215,6 +215,121 @@ def knn2_l2(q, t, ratio=0.65):
     return idx, dist, counts[0]
 
 
+def _pair_outputs(nq, dev, want_matches=True):
+    idx = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+    dist = torch.empty((nq, 2), dtype=torch.float32, device=dev)
+    start = torch.zeros((1,), dtype=torch.int64, device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    return idx, dist, start, cnt
+
+
+def _as_dev(a, dtype, device):
+    t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+    if t.dtype != dtype:
+        raise IsxError(f"expected {dtype} descriptors, got {t.dtype}")
+    return t.to(device).contiguous()
+
+
+def knn2_hamming(q, t, ratio=0.65, device=None):
+    """Opt-in: cv2.BFMatcher(cv2.NORM_HAMMING).knnMatch(q, t, k=2) + Lowe ratio for uint8 (binary)
+    descriptors of up to 64 bytes.  Returns idx (nq,2) int32, dist (nq,2) float32, good_count tensor."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    nq, nt = q.shape[0], t.shape[0]
+    if nq == 0 or nt == 0:
+        raise IsxError("knn2_hamming needs non-empty query and train sets")
+    d = q.shape[1]
+    if t.shape[1] != d or d > 64:
+        raise IsxError("descriptor widths differ or exceed 64 bytes")
+    d_pad = 32 if d <= 32 else 64
+    with torch.cuda.device(device):
+        both = torch.cat([_as_dev(q, torch.uint8, device), _as_dev(t, torch.uint8, device)], 0)
+        if d_pad != d:
+            both = torch.nn.functional.pad(both, (0, d_pad - d))
+        both = both.contiguous()
+        items = torch.tensor([[0, nq, nq, nt]], dtype=torch.int32, device=device)
+        idx, dist, start, cnt = _pair_outputs(nq, device)
+        check(_lib.lib().isx_knn2_hamming_items(_ptr(both), d_pad, _ptr(items), 1, nq, nt, float(ratio), _ptr(idx),
+                                                _ptr(dist), _ptr(start), _ptr(cnt), _stream()))
+    return idx, dist, cnt[0]
+
+
+def knn2_f32(q, t, ratio=0.65, device=None):
+    """cv2.BFMatcher().knnMatch(q, t, k=2) + Lowe ratio for float32 descriptors that are not integer
+    valued (fp32 MFMA path, 1e-4 relative distance gate).  Widths up to 128 (zero padded to 32/64/128)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    nq, nt = q.shape[0], t.shape[0]
+    if nq == 0 or nt == 0:
+        raise IsxError("knn2_f32 needs non-empty query and train sets")
+    d = q.shape[1]
+    if t.shape[1] != d or d > 128:
+        raise IsxError("descriptor widths differ or exceed 128")
+    d_pad = 32 if d <= 32 else (64 if d <= 64 else 128)
+    with torch.cuda.device(device):
+        both = torch.cat([_as_dev(q, torch.float32, device), _as_dev(t, torch.float32, device)], 0)
+        if d_pad != d:
+            both = torch.nn.functional.pad(both, (0, d_pad - d))
+        both = both.contiguous()
+        nrm = torch.empty((nq + nt,), dtype=torch.float32, device=device)
+        L = _lib.lib()
+        check(L.isx_f32_norms(_ptr(both), nq + nt, d_pad, _ptr(nrm), _stream()))
+        items = torch.tensor([[0, nq, nq, nt]], dtype=torch.int32, device=device)
+        idx, dist, start, cnt = _pair_outputs(nq, device)
+        check(L.isx_knn2_f32_items(_ptr(both), _ptr(nrm), d_pad, _ptr(items), 1, nq, float(ratio), _ptr(idx),
+                                   _ptr(dist), _ptr(start), _ptr(cnt), _stream()))
+    return idx, dist, cnt[0]
+
+
+def alt_item_counts(des_list, items_of, kind, ratio, device=None):
+    """Batched good-match counts with the Hamming ("hamming", uint8) or float32 ("f32") matcher.
+    des_list: per-image (n_i, d) arrays (None/empty allowed); items_of(starts, counts) -> (m,4) int32 work
+    items in the concatenated row space.  Returns an int32 device tensor of m counts."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    dtype = torch.uint8 if kind == "hamming" else torch.float32
+    tens, counts, d = [], [], None
+    for a in des_list:
+        if a is None or len(a) == 0:
+            counts.append(0)
+            continue
+        t = _as_dev(a, dtype, device)
+        d = t.shape[1] if d is None else d
+        if t.shape[1] != d:
+            raise IsxError("all descriptor arrays must share their width")
+        tens.append(t)
+        counts.append(t.shape[0])
+    if d is None:
+        raise IsxError("no descriptors given")
+    limit = 64 if kind == "hamming" else 128
+    if d > limit:
+        raise IsxError(f"descriptor width {d} exceeds {limit}")
+    d_pad = 32 if d <= 32 else (64 if d <= 64 else 128)
+    starts = np.concatenate([[0], np.cumsum(counts)])[:-1]
+    items = np.ascontiguousarray(items_of(starts, np.asarray(counts)), np.int32).reshape(-1, 4)
+    m = len(items)
+    with torch.cuda.device(device):
+        out = torch.zeros((m,), dtype=torch.int32, device=device)
+        if m == 0:
+            return out
+        allrows = torch.cat(tens, 0)
+        if d_pad != d:
+            allrows = torch.nn.functional.pad(allrows, (0, d_pad - d))
+        allrows = allrows.contiguous()
+        items_dev = torch.from_numpy(items).to(device)
+        L = _lib.lib()
+        max_nq, max_nt = int(items[:, 1].max()), int(items[:, 3].max())
+        if kind == "hamming":
+            check(L.isx_knn2_hamming_items(_ptr(allrows), d_pad, _ptr(items_dev), m, max_nq, max_nt, float(ratio),
+                                           None, None, None, _ptr(out), _stream()))
+        else:
+            nrm = torch.empty((allrows.shape[0],), dtype=torch.float32, device=device)
+            check(L.isx_f32_norms(_ptr(allrows), allrows.shape[0], d_pad, _ptr(nrm), _stream()))
+            check(L.isx_knn2_f32_items(_ptr(allrows), _ptr(nrm), d_pad, _ptr(items_dev), m, max_nq, float(ratio),
+                                       None, None, None, _ptr(out), _stream()))
+    return out
+
+
 def ratio_compact(idx, dist, ratio):
     """filter_matches as device arrays: (good_q, good_t) int32 tensors in query order (one sync to
     learn the count)."""

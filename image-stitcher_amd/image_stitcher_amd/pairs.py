@@ -59,9 +59,11 @@ def all_gather_descriptors(local_des, group=None):
     world = dist.get_world_size(group)
     if world == 1:
         return local_des
-    out = torch.empty((world,) + tuple(local_des.shape), dtype=local_des.dtype, device=local_des.device)
+    # concatenated (not stacked) output shape: the form both RCCL and gloo accept
+    out = torch.empty((world * local_des.shape[0],) + tuple(local_des.shape[1:]), dtype=local_des.dtype,
+                      device=local_des.device)
     dist.all_gather_into_tensor(out, local_des.contiguous(), group=group)
-    return out.reshape((-1,) + tuple(local_des.shape[1:]))
+    return out
 
 
 def gather_counts(local_counts, n_pairs_total, rank, world, group=None):

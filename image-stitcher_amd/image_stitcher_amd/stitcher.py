@@ -11,7 +11,9 @@ Deliberate differences from the reference:
   * log_level=0 switches logging off instead of raising AttributeError (stitcher.py:69-70);
   * dropping empty images does not touch self.filepaths when `images=` was given (stitcher.py:275);
   * matcher=1 (FLANN, approximate and randomised in cv2) is served by the exact brute-force kernel;
-  * mosaics are returned as DeviceImage (array-like; np.asarray() downloads) unless resident=False.
+  * mosaics are returned as DeviceImage (array-like; np.asarray() downloads) unless resident=False;
+  * keyword-only extensions: detector=, device=, resident=, norm= ('hamming' opts in to the XOR/popcount
+    matcher; the default 'l2' is what the reference's cv2.BFMatcher() computes for every algorithm).
 """
 import copy
 import logging
@@ -107,7 +109,7 @@ class Stitcher:
                  blend_processor=lambda x: x,
                  blender=1,
                  ref_image_contrib=0.5,  # Used in alpha blending
-                 *, detector=None, device=None, resident=True):
+                 *, detector=None, device=None, resident=True, norm="l2"):
         options = {
             "log_level": [logging.DEBUG, logging.INFO, logging.WARNING],
             "algorithm": ["sift", "orb", "akaze"],
@@ -146,6 +148,9 @@ class Stitcher:
         self.logger.info(f"Using {options['blender'][self.blender].upper()} blender")
         self.device = torch.device(device) if device is not None else None
         self.resident = resident
+        if norm not in ("l2", "hamming"):
+            raise ValueError("norm must be 'l2' (what the reference's cv2.BFMatcher() computes) or 'hamming'")
+        self.norm = norm  # extension: 'hamming' = cv2.BFMatcher(cv2.NORM_HAMMING) for binary descriptors
 
     # ---- plumbing -------------------------------------------------------------------------------
     @property
@@ -171,8 +176,27 @@ class Stitcher:
         if len(descriptors_1) == 0 or len(descriptors_2) == 0:
             return list()  # cv2 knnMatch returns [] for an empty query or train set
         with torch.cuda.device(self._dev()):
-            idx, dist, count = ops.knn2_l2(descriptors_1, descriptors_2, self.lowes_ratio_threshold)
+            kind = self._matcher_kind(descriptors_1)
+            if kind == "hamming":
+                idx, dist, count = ops.knn2_hamming(descriptors_1, descriptors_2, self.lowes_ratio_threshold, self._dev())
+            elif kind == "f32":
+                idx, dist, count = ops.knn2_f32(descriptors_1, descriptors_2, self.lowes_ratio_threshold, self._dev())
+            else:
+                idx, dist, count = ops.knn2_l2(descriptors_1, descriptors_2, self.lowes_ratio_threshold)
         return KnnMatches(idx, dist, count)
+
+    def _matcher_kind(self, des):
+        """'int' = exact int8-MFMA L2 (uint8, or integer-valued float32 as cv2.SIFT returns), 'f32' = fp32-MFMA
+        L2 for any other float descriptors, 'hamming' = opt-in XOR/popcount for uint8."""
+        a = des if isinstance(des, np.ndarray) else np.asarray(des)
+        if a.dtype == np.uint8:
+            return "hamming" if self.norm == "hamming" else "int"
+        if self.norm == "hamming":
+            raise ValueError("norm='hamming' needs uint8 (binary) descriptors")
+        if a.dtype == np.float32:
+            integer = bool(np.all(a == np.rint(a))) and float(a.min(initial=0)) >= 0 and float(a.max(initial=0)) <= 255
+            return "int" if integer else "f32"
+        raise ValueError(f"unsupported descriptor dtype {a.dtype}")
 
     @timer
     def filter_matches(self, matches):
@@ -437,10 +461,17 @@ class ArbitraryStitcher(Stitcher):
         rank = dist.get_rank(self.dist_group) if world > 1 else 0
         pairs = unordered_pairs(n, self.consecutive_range)
         with torch.cuda.device(dev):
-            P = ops.prepare_descriptors(self.des, device=dev)
             mine = shard_pairs(pairs, rank, world)
-            items = directed_items(mine, P.starts, P.counts)
-            c = ops.knn2_l2_items(P, items, self.lowes_ratio_threshold).view(-1, 2)
+            kinds = {self._matcher_kind(d) for d in self.des if d is not None and len(d)}
+            kind = "f32" if "f32" in kinds else (kinds.pop() if kinds else "int")
+            if kind == "int":
+                P = ops.prepare_descriptors(self.des, device=dev)
+                items = directed_items(mine, P.starts, P.counts)
+                c = ops.knn2_l2_items(P, items, self.lowes_ratio_threshold).view(-1, 2)
+            else:
+                des = self.des if kind == "hamming" else [None if d is None else np.asarray(d, np.float32) for d in self.des]
+                c = ops.alt_item_counts(des, lambda st, ct: directed_items(mine, st, ct), kind,
+                                        self.lowes_ratio_threshold, dev).view(-1, 2)
             allc = gather_counts(c, len(pairs), rank, world, self.dist_group)
             if world > 1:
                 box = [allc.cpu().numpy() if rank == 0 else None]

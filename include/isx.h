@@ -99,6 +99,24 @@ int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, int 
                             const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
                             int32_t *count_out_dev, int flags, void *stream);
 
+/* Opt-in Hamming matcher (XOR + popcount): the parity target is cv2.BFMatcher(cv2.NORM_HAMMING).knnMatch(k=2)
+ * -- NOT what the reference runs by default (stitcher.py:85 builds cv2.BFMatcher(), i.e. L2, for ORB too).
+ *   desc_dev : rows x d_pad bytes (d_pad 32 or 64; shorter descriptors zero padded on both sides)
+ *   distance = popcount as float32; ties -> lowest train index; outputs as isx_knn2_l2_items
+ *   max_nt   : max over items of nt (< 2^18, cv2's own limit) */
+int isx_knn2_hamming_items(const uint8_t *desc_dev, int d_pad, const isx_knn_item *items_dev, int n_items,
+                           int max_nq, int max_nt, double ratio, int32_t *idx_out_dev, float *dist_out_dev,
+                           const int64_t *out_start_dev, int32_t *count_out_dev, void *stream);
+
+/* float32 L2 matcher for descriptors that are not integer valued (stitcher.py:106-116 with float
+ * descriptors; cv2.SIFT's are integer valued and take the exact path above).  fp32 MFMA, ranking on
+ * na + nb - 2ab, winners' distances recomputed directly.  Gate: 1e-4 relative distance.
+ *   desc_dev : rows x d float32 (d = 32, 64 or 128), nrm_dev: rows float32 from isx_f32_norms */
+int isx_f32_norms(const float *desc_dev, int64_t rows, int d, float *nrm_out_dev, void *stream);
+int isx_knn2_f32_items(const float *desc_dev, const float *nrm_dev, int d, const isx_knn_item *items_dev,
+                       int n_items, int max_nq, double ratio, int32_t *idx_out_dev, float *dist_out_dev,
+                       const int64_t *out_start_dev, int32_t *count_out_dev, void *stream);
+
 /* Stitcher.filter_matches as a list (stitcher.py:118-127): stable compaction, in query order, of the rows
  * of a kNN-2 result that pass the ratio test (single-match rows are kept unconditionally, :125-126).
  * good_q/good_t: nq int32 each (capacity); count_out_dev: 1 int32 = len(good_matches). */

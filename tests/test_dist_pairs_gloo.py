@@ -1,0 +1,81 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU get_collections plumbing in image_stitcher_amd.pairs:
+pair sharding (pair p -> rank p % world), all_gather of descriptor shards, gather of the per-pair counts,
+host union-find.  The per-pair counts come from the CPU oracle here (there is no GPU in this test); on the
+GPU box the same functions run over RCCL with the HIP kernel producing the counts (bench.py --gpus N)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_img, kp, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from image_stitcher_amd import pairs as prs
+        from image_stitcher_amd.synthetic import overlapping_crops_descriptors
+        from oracle import orc
+        des, scene_of = overlapping_crops_descriptors(seed=5, n_scenes=2, imgs_per_scene=n_img // 2, kp=kp, step=kp // 6)
+        per = n_img // world
+        local = torch.from_numpy(des[rank * per:(rank + 1) * per].copy())       # this rank's "detected" shard
+        full = prs.all_gather_descriptors(local).numpy()
+        assert np.array_equal(full, des)
+        all_pairs = prs.unordered_pairs(n_img)
+        mine = prs.shard_pairs(all_pairs, rank, world)
+        c = np.array([[orc.match_count(full[i], full[j], 0.65), orc.match_count(full[j], full[i], 0.65)] for i, j in mine],
+                     np.int32).reshape(-1, 2)
+        allc = prs.gather_counts(torch.from_numpy(c), len(all_pairs), rank, world)
+        if rank == 0:
+            comps, _ = prs.components_from_counts(n_img, all_pairs, allc[:, 0].numpy(), allc[:, 1].numpy(), 5)
+            np.save(out_path, np.array([allc.numpy(), np.array(comps, dtype=object)], dtype=object), allow_pickle=True)
+        else:
+            assert allc is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_get_collections_matches_single_process(tmp_path, orc, world):
+    from image_stitcher_amd import pairs as prs
+    from image_stitcher_amd.synthetic import overlapping_crops_descriptors
+    n_img, kp = 6, 96
+    out = str(tmp_path / "r0.npy")
+    mp.spawn(_worker, args=(world, _free_port(), n_img, kp, out), nprocs=world, join=True)
+    allc, comps = np.load(out, allow_pickle=True)  # written by this test itself
+    des, scene_of = overlapping_crops_descriptors(seed=5, n_scenes=2, imgs_per_scene=n_img // 2, kp=kp, step=kp // 6)
+    all_pairs = prs.unordered_pairs(n_img)
+    exp = np.array([[orc.match_count(des[i], des[j], 0.65), orc.match_count(des[j], des[i], 0.65)] for i, j in all_pairs], np.int32)
+    assert np.array_equal(np.asarray(allc, np.int32), exp)
+    exp_comps, _ = prs.components_from_counts(n_img, all_pairs, exp[:, 0], exp[:, 1], 5)
+    assert [list(c) for c in comps] == exp_comps
+    truth = sorted(sorted(np.nonzero(scene_of == s)[0].tolist()) for s in range(2))
+    assert sorted(sorted(c) for c in exp_comps) == truth
+
+
+def test_pair_sharding_covers_every_pair_once():
+    from image_stitcher_amd import pairs as prs
+    p = prs.unordered_pairs(37)
+    assert len(p) == 37 * 36 // 2
+    for world in (1, 2, 4, 8):
+        got = np.concatenate([prs.shard_pairs(p, r, world) for r in range(world)])
+        assert len(got) == len(p) and len({(a, b) for a, b in got}) == len(p)
+        sizes = [len(prs.shard_pairs(p, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+    q = prs.unordered_pairs(10, consecutive_range=2)
+    assert all(0 < b - a <= 2 for a, b in q) and len(q) == 9 + 8
+    it = prs.directed_items(p[:3], np.arange(37) * 10, np.full(37, 10))
+    assert it.shape == (6, 4) and (it[0] == [0, 10, 10, 10]).all() and (it[1] == [10, 10, 0, 10]).all()

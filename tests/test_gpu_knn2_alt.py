@@ -1,0 +1,82 @@
+"""GPU parity of the two non-default matchers (through the C ABI) vs the CPU oracle:
+Hamming (bit exact) and float32 L2 (1e-4 relative distance, BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _planted(rng, nq, nt, d, flips=6):
+    t = rng.integers(0, 256, (nt, d), dtype=np.uint8)
+    q = rng.integers(0, 256, (nq, d), dtype=np.uint8)
+    k = min(nq, nt) // 2
+    src = rng.permutation(nt)[:k]
+    q[:k] = t[src]
+    for i in range(k):  # flip a few bits of the planted copies
+        for b in rng.integers(0, d * 8, flips):
+            q[i, b // 8] ^= np.uint8(1 << (b % 8))
+    return q, t
+
+
+@pytest.mark.parametrize("nq,nt,d", [(500, 500, 32), (1, 1, 32), (3, 2, 32), (257, 1031, 32), (700, 650, 61), (64, 300, 64)])
+def test_hamming_bit_exact(cuda, orc, nq, nt, d):
+    import torch
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(nq + 3 * nt + d)
+    q, t = _planted(rng, nq, nt, d)
+    if nt > 40:
+        t[7] = t[3]       # duplicate rows: equal distances must resolve to the lower index
+        t[nt - 1] = t[20]
+    for ratio in (0.65, 0.8):
+        idx, dist, cnt = ops.knn2_hamming(q, t, ratio)
+        torch.cuda.synchronize()
+        ridx, rdist = orc.knn2(q, t, norm=orc.NORM_HAMMING)
+        assert np.array_equal(idx.cpu().numpy(), ridx)
+        assert np.array_equal(dist.cpu().numpy().view(np.int32), rdist.view(np.int32))
+        gq, _ = orc.ratio_filter(ridx, rdist, ratio)
+        assert int(cnt.item()) == len(gq)
+
+
+@pytest.mark.parametrize("nq,nt,d", [(300, 500, 128), (1, 1, 128), (5, 2, 64), (129, 257, 61), (1000, 1200, 128)])
+def test_f32_within_tolerance(cuda, orc, nq, nt, d):
+    import torch
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(nq + nt + d)
+    t = rng.gamma(1.0, 30.0, (nt, d)).astype(np.float32)  # non-integer, SIFT-like magnitudes
+    q = rng.gamma(1.0, 30.0, (nq, d)).astype(np.float32)
+    k = min(nq, nt) // 2
+    q[:k] = t[rng.permutation(nt)[:k]] + rng.normal(0, 2.0, (k, d)).astype(np.float32)
+    idx, dist, cnt = ops.knn2_f32(q, t, 0.65)
+    torch.cuda.synchronize()
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    ridx, rdist = orc.knn2(q, t)
+    K = min(2, nt)
+    rel = np.abs(dist[:, :K] - rdist[:, :K]) / np.maximum(rdist[:, :K], 1e-6)
+    assert rel.max() <= 1e-4, f"max relative distance error {rel.max():.3g}"   # the north_star gate
+    # indices agree wherever the oracle's own neighbours are separated by more than the tolerance
+    if nt >= 3:
+        clear = (rdist[:, 1] - rdist[:, 0]) > 1e-4 * rdist[:, 1]
+        assert np.array_equal(idx[clear, 0], ridx[clear, 0])
+    else:
+        assert np.array_equal(idx[:, :K], ridx[:, :K])
+    if nt == 1:
+        assert (idx[:, 1] == -1).all()
+    gq, _ = orc.ratio_filter(ridx, rdist, 0.65)
+    assert abs(int(cnt.item()) - len(gq)) <= max(1, len(gq) // 200)
+
+
+def test_f32_integer_valued_matches_exact_path(cuda, orc):
+    """On integer-valued floats every f32 operation is exact, so the fp32-MFMA path must agree bit for bit
+    with the oracle (and with the int8 path)."""
+    import torch
+    from image_stitcher_amd import ops
+    from image_stitcher_amd.synthetic import overlapping_crops_descriptors
+    des, _ = overlapping_crops_descriptors(seed=21, n_scenes=1, imgs_per_scene=2, kp=900, step=300)
+    q, t = des[0].astype(np.float32), des[1].astype(np.float32)
+    idx, dist, cnt = ops.knn2_f32(q, t, 0.65)
+    idx2, dist2, cnt2 = ops.knn2_l2(q, t, 0.65)
+    torch.cuda.synchronize()
+    ridx, rdist = orc.knn2(q, t)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(idx2.cpu().numpy(), ridx)
+    assert np.array_equal(dist.cpu().numpy().view(np.int32), rdist.view(np.int32))
+    assert int(cnt.item()) == int(cnt2.item())
