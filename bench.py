@@ -15,10 +15,13 @@ when the timed region starts.  The pair space is fixed and split over the ranks 
 "strong".
 
 The JSON line also carries:
-  roofline     -- the dominant kernel (knn2_l2_kernel<4>) against the dense int8 MFMA peak, from the
+  roofline     -- the dominant kernel (knn2_count_kernel<4>) against the dense int8 MFMA peak, from the
                   kernel duration measured live with HIP events around the launch;
   cpu_baseline -- the CPU oracle's port of cv2.BFMatcher().knnMatch(float32) + ratio loop, timed on
-                  a bounded sample of the same pairs on this host (rank 0, N=1 only).
+                  a bounded sample of the same pairs on this host (rank 0, N=1 only);
+  stitch       -- (N=1 only, skip with --no-stitch) the second half of BASELINE.json's metric, "HD
+                  consecutive stitch Hz": a ConsecutiveStitcher.stitch_consecutive loop over synthetic
+                  1920x1080 BGR frames (BASELINE.json configs[1]); see stitch_workload() below.
 """
 import argparse
 import json
@@ -46,7 +49,96 @@ def parse():
     ap.add_argument("--kp", type=int, default=4096)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stitch", action="store_true", help="skip the 1080p consecutive-stitch leg")
+    ap.add_argument("--stitch-frames", type=int, default=8)
     return ap.parse_args()
+
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
+
+
+class _TimedDetector:
+    """Wraps the CPU feature detector (out of scope, stays on the CPU as in the reference) to account its time."""
+
+    def __init__(self, det):
+        self.det, self.seconds, self.calls = det, 0.0, 0
+
+    def detectAndCompute(self, image, mask=None):
+        t0 = time.perf_counter()
+        r = self.det.detectAndCompute(image, mask)
+        self.seconds += time.perf_counter() - t0
+        self.calls += 1
+        return r
+
+
+def stitch_workload(dev, n_frames):
+    """BASELINE.json configs[1]: ConsecutiveStitcher on a 1080p stream, ORB-like binary descriptors,
+    consecutive_range=2, default blender (gradient) and type (affine partial), one MI355X.  Frames are
+    crops of a seeded procedural texture along a path (15 % translation per frame, +-1 degree).  Hz is
+    frames / wall second exactly as the reference's tests/test.py:82-89 prints it; detection runs on the
+    CPU (cv2 ORB when importable, else the numpy stand-in of image_stitcher_amd.detect) and its share is
+    reported so that the GPU hot path can be read on its own."""
+    import tempfile
+    from image_stitcher_amd import ConsecutiveStitcher, ops
+    from image_stitcher_amd.synthetic import crop_path, procedural_world
+    try:
+        from image_stitcher_amd.detect import make_detector
+        det, det_name = make_detector(1), "cv2.ORB_create()"
+    except ImportError:
+        from image_stitcher_amd.detect import NumpyOrbLite
+        det, det_name = NumpyOrbLite(nfeatures=1500), "NumpyOrbLite (numpy/scipy stand-in, cv2 absent)"
+    det = _TimedDetector(det)
+    world = procedural_world(seed=42, h=2160, w=1920 + int(0.15 * 1920 * (n_frames + 4)) + 400)
+    frames, _ = crop_path(world, n_frames + 3, (1080, 1920), step_frac=0.15, max_rot_deg=1.0, seed=43)
+    st = ConsecutiveStitcher(log_level=3, output_dir=tempfile.mkdtemp(prefix="isx_bench_"), algorithm=1,
+                             consecutive_range=2, detector=det)
+    warm = 3
+    for f in frames[:warm]:
+        st.stitch_consecutive(f)
+    torch.cuda.synchronize()
+    det.seconds, det.calls = 0.0, 0
+    ok = 0
+    t0 = time.perf_counter()
+    for f in frames[warm:]:
+        ok += st.stitch_consecutive(f) is not None
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    k = len(frames) - warm
+    # kernel-level roofline of warp + feather blend on one representative 1080p frame (HIP events on the
+    # launch stream): algorithmic bytes = frame read + mosaic ROI read + write (SURVEY 8d)
+    img = torch.from_numpy(frames[-1]).to(dev)
+    H, W = 1080 * 3, 1920 * 3
+    M = np.array([[0.9998, -0.0175, 300.0], [0.0175, 0.9998, 12.0]])
+    rect = (1920 + 250, 1080 - 40, 2030, 1190)
+    wbuf = torch.empty((rect[3], rect[2], 3), dtype=torch.uint8, device=dev)
+    roi = torch.full((rect[3], rect[2], 3), 90, dtype=torch.uint8, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    for _ in range(3):
+        ops.warp(img, M, False, rect, src_xy=(1920, 1080), out=wbuf)
+        ops.gradient_blend_roi(wbuf, roi)
+    e0.record()
+    for _ in range(reps):
+        ops.warp(img, M, False, rect, src_xy=(1920, 1080), out=wbuf)
+        ops.gradient_blend_roi(wbuf, roi)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    alg_bytes = img.numel() + 2 * roi.numel()
+    executed_bytes = img.numel() + 2 * wbuf.numel() + 2 * roi.numel() + roi.numel()  # warp writes, extents+blend read wbuf
+    return {
+        "metric": "HD consecutive stitch Hz", "value": k / wall, "unit": "frames/s",
+        "frames": k, "stitched": int(ok), "ms_per_frame": wall / k * 1e3,
+        "detector": det_name, "detector_ms_per_frame": det.seconds / k * 1e3, "detector_calls": det.calls,
+        "hz_excluding_cpu_detection": k / max(wall - det.seconds, 1e-9),
+        "config": {"workload": "ConsecutiveStitcher 1920x1080 BGR stream, consecutive_range=2, type=0 (affine partial), "
+                               "blender=1 (gradient), binary descriptors matched with L2 as the reference's cv2.BFMatcher() does",
+                   "final_mosaic_shape": [int(v) for v in st.refs[-1].shape]},
+        "roofline": {"bound": "hbm", "achieved": alg_bytes / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "warp_kernel<3,false> + ext/row/col_extent + gradient_blend_kernel<3> (one frame)",
+                     "kernel_us": us, "algorithmic_bytes": int(alg_bytes), "executed_bytes": int(executed_bytes)},
+    }
 
 
 def cpu_baseline(des, pairs, ratio, seconds):
@@ -161,7 +253,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "int8 (exact int32 accumulate)",
+            "dtype": "i8",
             "data": "synthetic",
             "config": {"workload": f"ArbitraryStitcher.get_collections all-pairs: {n} images x {kp} SIFT-like kp x {d}-d "
                                    f"({pairs_per_step} unordered pairs, both directions, ratio {ratio}, min_match {min_match})",
@@ -169,11 +261,14 @@ def main():
                        "components_correct": bool(ok)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                          "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic,
-                         "kernel": "knn2_l2_kernel<4>", "kernel_ms": k_ms,
+                         "kernel": "knn2_count_kernel<4>", "kernel_ms": k_ms,
                          "note": "int8 MFMA ops; algorithmic 2*Nq*Nt*D per unordered pair (the kernel executes 2x: one pass per direction)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(des, all_pairs, ratio, args.cpu_seconds)
+        if world == 1 and not args.no_stitch:
+            del des, local
+            line["stitch"] = stitch_workload(dev, args.stitch_frames)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,57 @@
+// Back-to-back timing of the image kernels through the C ABI (no host gaps between launches), 1080p BGR.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/img_bench.hip -Iinclude -Limage-stitcher_amd/image_stitcher_amd/lib -lisx_hip -Wl,-rpath,'$ORIGIN/../../image-stitcher_amd/image_stitcher_amd/lib' -o tools/bin/img_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "isx.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+#define IK(x) do { int r = (x); if (r < 0) { printf("isx error %s line %d\n", isx_last_error(), __LINE__); exit(1);} } while (0)
+
+template <typename F> static float time_us(int reps, F f) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 5; i++) f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; i++) f();
+    CK(hipEventRecord(b));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms * 1e3f / reps;
+}
+
+int main() {
+    const int sh = 1080, sw = 1920, C = 3;
+    const int dw = 2030, dh = 1190;             // warped region (frame bbox + margins)
+    std::vector<uint8_t> h((size_t)sh * sw * C);
+    for (size_t i = 0; i < h.size(); i++) h[i] = 12 + (uint8_t)((i * 2654435761u) >> 25);
+    uint8_t *src, *wbuf, *roi; int32_t *bb, *ext;
+    CK(hipMalloc(&src, h.size())); CK(hipMemcpy(src, h.data(), h.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&wbuf, (size_t)dw * dh * C)); CK(hipMalloc(&roi, (size_t)dw * dh * C));
+    CK(hipMemset(roi, 90, (size_t)dw * dh * C));
+    CK(hipMalloc(&bb, 5 * 4)); CK(hipMalloc(&ext, (2 * dh + 2 * dw) * 4));
+    const double M[6] = {0.9998, -0.0175, 300.0, 0.0175, 0.9998, 12.0};
+    const int sx = 1920, sy = 1080, dx0 = 1920 + 250, dy0 = 1080 - 40;
+    const double src_b = (double)sh * sw * C, roi_b = (double)dw * dh * C;
+    float t;
+    t = time_us(200, [&] { IK(isx_warp(src, sh, sw, C, sw * C, sx, sy, M, 0, wbuf, dw * C, dx0, dy0, dw, dh, nullptr, 0)); });
+    printf("warp (no bbox)        %7.2f us  %6.0f GB/s (read frame + write region)\n", t, (src_b + roi_b) / t / 1e3);
+    t = time_us(200, [&] { IK(isx_bbox_reset(bb, 0)); IK(isx_warp(src, sh, sw, C, sw * C, sx, sy, M, 0, wbuf, dw * C, dx0, dy0, dw, dh, bb, 0)); });
+    printf("warp + bbox           %7.2f us  %6.0f GB/s\n", t, (src_b + roi_b) / t / 1e3);
+    t = time_us(200, [&] { IK(isx_bbox_nonzero(src, sh, sw, C, sw * C, bb, 0)); });
+    printf("bbox_nonzero 1080p    %7.2f us  %6.0f GB/s (read frame)\n", t, src_b / t / 1e3);
+    t = time_us(200, [&] { IK(isx_gradient_blend(wbuf, dw * C, roi, dw * C, dh, dw, C, 10, ext, 0)); });
+    printf("gradient_blend (4 k)  %7.2f us  %6.0f GB/s (2 reads of warped + read/write roi)\n", t, 4 * roi_b / t / 1e3);
+    t = time_us(200, [&] { IK(isx_alpha_blend(wbuf, dw * C, roi, dw * C, roi, dw * C, dh, dw, C, 0.5, 0)); });
+    printf("alpha_blend           %7.2f us  %6.0f GB/s (2 reads + 1 write)\n", t, 3 * roi_b / t / 1e3);
+    t = time_us(200, [&] {
+        IK(isx_bbox_reset(bb, 0));
+        IK(isx_warp(src, sh, sw, C, sw * C, sx, sy, M, 0, wbuf, dw * C, dx0, dy0, dw, dh, bb, 0));
+        IK(isx_gradient_blend(wbuf, dw * C, roi, dw * C, dh, dw, C, 10, ext, 0));
+    });
+    printf("frame: warp+bbox+gradient blend %7.2f us  algorithmic %6.0f GB/s (frame + 2 x roi = %.1f MB)\n", t,
+           (src_b + 2 * roi_b) / t / 1e3, (src_b + 2 * roi_b) / 1e6);
+    t = time_us(200, [&] { CK(hipMemcpyAsync(roi, wbuf, (size_t)dw * dh * C, hipMemcpyDeviceToDevice, 0)); });
+    printf("memcpy d2d roi        %7.2f us  %6.0f GB/s (read + write)\n", t, 2 * roi_b / t / 1e3);
+    return 0;
+}
