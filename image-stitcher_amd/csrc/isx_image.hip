@@ -33,54 +33,61 @@ __device__ __forceinline__ int wave_max(int v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Row segments.  A wave moves 64 pixels of one row as a byte stream of 64*C bytes: lane k loads / stores
-// the dword at byte 4k (any alignment: crops start at arbitrary x) and the pixels are cut out of / packed
-// into that stream with two cross-lane reads.  One dword instruction per 64 pixels instead of C byte
-// instructions, which is what lets these byte kernels approach the HBM rate.
+// Pixel quads.  A lane owns 4 horizontally adjacent pixels = 4*C contiguous bytes and moves them with one
+// unaligned 12-byte (C=3) / 4-byte (C=1) access (crops start at arbitrary x, so no alignment can be
+// assumed; gfx950 global accesses are byte-addressable in the default unaligned mode).  A wave therefore
+// covers 256 pixels of a row (768 B per instruction for BGR) with no cross-lane traffic.
 // ------------------------------------------------------------------------------------------------
+typedef uint16_t u16u __attribute__((aligned(1)));
 typedef uint32_t u32u __attribute__((aligned(1)));
 typedef uint64_t u64u __attribute__((aligned(1)));
+struct __attribute__((packed, aligned(1))) u96u {
+    uint32_t a, b, c;
+};
 
-// dword `lane` of a segment of `nbytes` valid bytes (0 beyond the end)
-__device__ __forceinline__ uint32_t seg_load(const uint8_t *__restrict__ base, int nbytes, int lane) {
-    const int o = 4 * lane;
-    uint32_t v = 0;
-    if (o + 4 <= nbytes) {
-        v = *(const u32u *)(base + o);
-    } else {
-        for (int j = 0; j < 4; j++)
-            if (o + j < nbytes) v |= (uint32_t)base[o + j] << (8 * j);
-    }
-    return v;
-}
-__device__ __forceinline__ void seg_store(uint8_t *__restrict__ base, int nbytes, int lane, uint32_t v) {
-    const int o = 4 * lane;
-    if (o + 4 <= nbytes) {
-        *(u32u *)(base + o) = v;
-    } else {
-        for (int j = 0; j < 4; j++)
-            if (o + j < nbytes) base[o + j] = (uint8_t)(v >> (8 * j));
-    }
-}
-// the C bytes of pixel `lane` (low bits) out of the dword stream
+// pixels x .. x+3 of a row (packed B | G<<8 | R<<16, or the gray byte); pixels at or beyond w read as 0
 template <int C>
-__device__ __forceinline__ uint32_t seg_pixel(uint32_t dw, int lane) {
-    const int b = C * lane, d0 = b >> 2, sh = (b & 3) * 8;
-    const uint32_t lo = __shfl(dw, d0), hi = __shfl(dw, d0 + 1);
-    const uint64_t v = ((uint64_t)hi << 32) | lo;
-    return (uint32_t)(v >> sh) & (C == 3 ? 0xFFFFFFu : 0xFFu);
-}
-// inverse: every lane gives its pixel, lane k gets dword k of the stream (lanes >= 16*C get garbage)
-template <int C>
-__device__ __forceinline__ uint32_t seg_pack(uint32_t px, int lane) {
-    if (C == 3) {
-        const int p0 = (4 * lane) / 3, off = (4 * lane) % 3;
-        const uint64_t a = __shfl(px, p0), b = __shfl(px, p0 + 1);
-        return (uint32_t)((a | (b << 24)) >> (8 * off));
+__device__ __forceinline__ void quad_load(const uint8_t *__restrict__ row, int x, int w, uint32_t (&px)[4]) {
+    const uint8_t *p = row + (int64_t)x * C;
+    if (x + 4 <= w) {
+        if (C == 3) {
+            const u96u v = *(const u96u *)p;
+            px[0] = v.a & 0xFFFFFFu;
+            px[1] = (v.a >> 24) | ((v.b & 0xFFFFu) << 8);
+            px[2] = (v.b >> 16) | ((v.c & 0xFFu) << 16);
+            px[3] = v.c >> 8;
+        } else {
+            const uint32_t v = *(const u32u *)p;
+            px[0] = v & 255u, px[1] = (v >> 8) & 255u, px[2] = (v >> 16) & 255u, px[3] = v >> 24;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            px[i] = 0u;
+            if (x + i < w)
+                for (int c = 0; c < C; c++) px[i] |= (uint32_t)p[i * C + c] << (8 * c);
+        }
     }
-    const uint32_t a = __shfl(px, 4 * lane), b = __shfl(px, 4 * lane + 1);
-    const uint32_t c = __shfl(px, 4 * lane + 2), d = __shfl(px, 4 * lane + 3);
-    return (a & 255u) | ((b & 255u) << 8) | ((c & 255u) << 16) | (d << 24);
+}
+template <int C>
+__device__ __forceinline__ void quad_store(uint8_t *__restrict__ row, int x, int w, const uint32_t (&px)[4]) {
+    uint8_t *p = row + (int64_t)x * C;
+    if (x + 4 <= w) {
+        if (C == 3) {
+            u96u v;
+            v.a = px[0] | (px[1] << 24);
+            v.b = (px[1] >> 8) | (px[2] << 16);
+            v.c = (px[2] >> 16) | (px[3] << 8);
+            *(u96u *)p = v;
+        } else {
+            *(u32u *)p = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (x + i < w)
+                for (int c = 0; c < C; c++) p[i * C + c] = (uint8_t)(px[i] >> (8 * c));
+    }
 }
 
 // bbox accumulator layout: {x0, y0, x1 (exclusive), y1 (exclusive), found}
@@ -94,11 +101,17 @@ __global__ void bbox_init_kernel(int32_t *bb) {
     }
 }
 
-// Workgroup-level bbox update (EVERY thread of a 256-thread block must call it): wave reduce, merge of
-// the 4 waves through LDS, then one guarded atomic per bound.  The guard reads the current bound first
-// (a stale value is only ever looser, so no needed update is skipped): without it tens of thousands of
-// waves serialise on five addresses (measured: 1.9 ms for one 1080p warp).
-__device__ __forceinline__ void bbox_block_accumulate(int minx, int miny, int maxx, int maxy, int32_t *bb) {
+// Bounding boxes are reduced in two kernels: every workgroup stores its partial box with plain stores
+// into a library-owned table, and a one-workgroup kernel on the same stream folds the table into the
+// caller's 5-int accumulator.  (Atomics on the accumulator itself serialise: all workgroups finish
+// together, read the same untouched bounds and then queue ~10^4 atomics on one cache line -- measured
+// +50 us on a 13 us warp.)  The table is per device and shared by every call: bbox-producing calls must
+// not overlap on one GPU (the host layer issues them on one stream).
+#define ISX_BBOX_MAX_BLOCKS 2048
+static __device__ int32_t g_bbox_partial[ISX_BBOX_MAX_BLOCKS * 4];
+
+// EVERY thread of a 256-thread block must call it
+__device__ __forceinline__ void bbox_block_partial(int minx, int miny, int maxx, int maxy) {
     __shared__ int red[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int a = wave_min(minx), b = wave_min(miny), c = wave_max(maxx), d = wave_max(maxy);
@@ -117,48 +130,80 @@ __device__ __forceinline__ void bbox_block_accumulate(int minx, int miny, int ma
             x1 = max(x1, red[w][2]);
             y1 = max(y1, red[w][3]);
         }
-        if (x1 >= 0) {
-            if (x0 < __hip_atomic_load(&bb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&bb[0], x0);
-            if (y0 < __hip_atomic_load(&bb[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&bb[1], y0);
-            if (x1 > __hip_atomic_load(&bb[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bb[2], x1);
-            if (y1 > __hip_atomic_load(&bb[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bb[3], y1);
-            if (__hip_atomic_load(&bb[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(&bb[4], 1);
+        int32_t *o = g_bbox_partial + 4 * blockIdx.x;
+        o[0] = x0, o[1] = y0, o[2] = x1, o[3] = y1;
+    }
+}
+
+__global__ void __launch_bounds__(256) bbox_finish_kernel(int n_blocks, int32_t *__restrict__ bb) {
+    int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
+    for (int i = threadIdx.x; i < n_blocks; i += 256) {
+        const int32_t *o = g_bbox_partial + 4 * i;
+        x0 = min(x0, o[0]);
+        y0 = min(y0, o[1]);
+        x1 = max(x1, o[2]);
+        y1 = max(y1, o[3]);
+    }
+    __shared__ int red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    x0 = wave_min(x0), y0 = wave_min(y0), x1 = wave_max(x1), y1 = wave_max(y1);
+    if (lane == 0) red[wave][0] = x0, red[wave][1] = y0, red[wave][2] = x1, red[wave][3] = y1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) {
+            x0 = min(x0, red[w][0]);
+            y0 = min(y0, red[w][1]);
+            x1 = max(x1, red[w][2]);
+            y1 = max(y1, red[w][3]);
+        }
+        if (x1 >= 0) { // merge into the caller's accumulator
+            bb[0] = min(bb[0], x0);
+            bb[1] = min(bb[1], y0);
+            bb[2] = max(bb[2], x1);
+            bb[3] = max(bb[3], y1);
+            bb[4] = 1;
         }
     }
 }
 
+template <int C>
+__device__ __forceinline__ void bbox_quad(const uint32_t (&px)[4], int x, int y, int &minx, int &miny, int &maxx,
+                                          int &maxy) {
+    // pixels outside the image were loaded / produced as 0 and never count
+    int first = -1, last = -1;
+#pragma unroll
+    for (int i = 3; i >= 0; i--)
+        if (gray_px<C>(px[i]) != 0) first = i;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (gray_px<C>(px[i]) != 0) last = i;
+    if (last >= 0) {
+        minx = min(minx, x + first);
+        maxx = max(maxx, x + last + 1);
+        miny = min(miny, y);
+        maxy = max(maxy, y + 1);
+    }
+}
+
 // reference utils/proc.py:34-45 get_corners_from_image (cv2.findNonZero + cv2.boundingRect on gray).
-// Tile = 64 pixels x 32 rows (wave w takes rows w, w+4, ...).  The grid is capped and every block walks
-// tiles blockIdx, blockIdx + grid, ...: its local box is then close to the global one, so after the
-// first few blocks have published, the guarded atomics of bbox_block_accumulate are skipped.
+// Tile = 256 pixels x 16 rows (wave w takes rows w, w+4, w+8, w+12; four 768-byte loads in flight).
 template <int C>
 __global__ void __launch_bounds__(256) bbox_nonzero_kernel(const uint8_t *__restrict__ img, int h, int w,
-                                                           int64_t pitch, int tiles_x, int n_tiles,
-                                                           int32_t *__restrict__ bb) {
+                                                           int64_t pitch, int tiles_x, int n_tiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int minx = INT_MAX, miny = INT_MAX, maxx = -1, maxy = -1;
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const int xs = (t % tiles_x) * 64, x = xs + lane, y0 = (t / tiles_x) * 32 + wave;
-        const int nvalid = min(64, w - xs);
-        uint32_t dw[8];
+        const int x = (t % tiles_x) * 256 + 4 * lane, y0 = (t / tiles_x) * 16 + wave;
+        uint32_t px[4][4];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
+        for (int i = 0; i < 4; i++) {
             const int y = y0 + 4 * i;
-            dw[i] = y < h ? seg_load(img + y * pitch + (int64_t)xs * C, nvalid * C, lane) : 0u;
+            quad_load<C>(img + (int64_t)min(y, h - 1) * pitch, x, y < h ? w : 0, px[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int y = y0 + 4 * i;
-            const uint32_t px = seg_pixel<C>(dw[i], lane);
-            if (lane < nvalid && gray_px<C>(px) != 0) { // rows beyond h loaded 0
-                minx = minx < x ? minx : x;
-                maxx = maxx > x + 1 ? maxx : x + 1;
-                miny = miny < y ? miny : y;
-                maxy = maxy > y + 1 ? maxy : y + 1;
-            }
-        }
+        for (int i = 0; i < 4; i++) bbox_quad<C>(px[i], x, y0 + 4 * i, minx, miny, maxx, maxy);
     }
-    bbox_block_accumulate(minx, miny, maxx, maxy, bb);
+    bbox_block_partial(minx, miny, maxx, maxy);
 }
 
 extern "C" int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int64_t pitch, int32_t *bbox_out_dev,
@@ -170,14 +215,15 @@ extern "C" int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int
     hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, bbox_out_dev);
     if (h > 0 && w > 0) {
         ISX_REQUIRE(img_dev, "null img_dev");
-        const int tiles_x = (w + 63) / 64;
-        const int64_t n_tiles = (int64_t)tiles_x * ((h + 31) / 32);
+        const int tiles_x = (w + 255) / 256;
+        const int64_t n_tiles = (int64_t)tiles_x * ((h + 15) / 16);
         ISX_REQUIRE(n_tiles < ((int64_t)1 << 31), "image too large");
-        const unsigned grid = (unsigned)(n_tiles < 1024 ? n_tiles : 1024);
+        const unsigned grid = (unsigned)(n_tiles < ISX_BBOX_MAX_BLOCKS ? n_tiles : ISX_BBOX_MAX_BLOCKS);
         if (c == 3)
-            hipLaunchKernelGGL((bbox_nonzero_kernel<3>), dim3(grid), dim3(256), 0, st, img_dev, h, w, pitch, tiles_x, (int)n_tiles, bbox_out_dev);
+            hipLaunchKernelGGL((bbox_nonzero_kernel<3>), dim3(grid), dim3(256), 0, st, img_dev, h, w, pitch, tiles_x, (int)n_tiles);
         else
-            hipLaunchKernelGGL((bbox_nonzero_kernel<1>), dim3(grid), dim3(256), 0, st, img_dev, h, w, pitch, tiles_x, (int)n_tiles, bbox_out_dev);
+            hipLaunchKernelGGL((bbox_nonzero_kernel<1>), dim3(grid), dim3(256), 0, st, img_dev, h, w, pitch, tiles_x, (int)n_tiles);
+        hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(256), 0, st, (int)grid, bbox_out_dev);
     }
     return isx_launch_status("bbox_nonzero_kernel");
 }
@@ -189,8 +235,7 @@ extern "C" int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int
 // rounded to nearest even.  The source is the UN-padded frame placed at (src_x, src_y) of the virtual
 // padded canvas (reference utils/proc.py:295-304), which is identical to sampling the zero-padded
 // canvas; only the destination rectangle [dx0,dx0+dw) x [dy0,dy0+dh) of the canvas is produced.
-// Interior pixels fetch the two taps of a row with ONE unaligned 8-byte (C=3) / 2-byte (C=1) load; the
-// output row segment is packed across lanes and stored as dwords.
+// Interior pixels fetch the two taps of a row with ONE unaligned 8-byte (C=3) / 2-byte (C=1) load.
 // ------------------------------------------------------------------------------------------------
 struct WarpParams {
     float m[9];
@@ -234,7 +279,6 @@ __device__ __forceinline__ uint32_t warp_pixel(const uint8_t *__restrict__ src, 
                 p11[c] = (uint32_t)(q1 >> (8 * (c + 3))) & 255u;
             }
         } else {
-            typedef uint16_t u16u __attribute__((aligned(1)));
             const uint32_t q0 = *(const u16u *)r0, q1 = *(const u16u *)r1;
             p00[0] = q0 & 255u;
             p01[0] = q0 >> 8;
@@ -263,40 +307,25 @@ __device__ __forceinline__ uint32_t warp_pixel(const uint8_t *__restrict__ src, 
     return px;
 }
 
-// Tile = 64 pixels x 16 rows (wave w takes rows w, w+4, w+8, w+12: four gathers in flight per lane); the
-// grid is capped and strided like bbox_nonzero_kernel so that the bbox atomics stay rare.
+// Tile = 256 pixels x 4 rows (one row per wave, a lane produces 4 adjacent pixels: eight gathers in
+// flight per lane, one 12-byte store).  Capped, strided grid; per-block partial bbox (see above).
 template <int C, bool PERSP>
 __global__ void __launch_bounds__(256) warp_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                   const WarpParams P, int tiles_x, int n_tiles,
-                                                   int32_t *__restrict__ bb) {
+                                                   const WarpParams P, int tiles_x, int n_tiles, int want_bbox) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int minx = INT_MAX, miny = INT_MAX, maxx = -1, maxy = -1;
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const int lx0 = (t % tiles_x) * 64, lx = lx0 + lane;
-        const int ly0 = (t / tiles_x) * 16 + wave;
-        const int nvalid = min(64, P.dw - lx0);
-        const int x = P.dx0 + lx;
+        const int lx = (t % tiles_x) * 256 + 4 * lane;
+        const int ly = (t / tiles_x) * 4 + wave;
+        if (ly >= P.dh) continue; // wave-uniform
         uint32_t px[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int ly = ly0 + 4 * i;
-            px[i] = (lx < P.dw && ly < P.dh) ? warp_pixel<C, PERSP>(src, P, x, P.dy0 + ly) : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int ly = ly0 + 4 * i;
-            if (ly < P.dh) // wave-uniform
-                seg_store(dst + (int64_t)ly * P.dpitch + (int64_t)lx0 * C, nvalid * C, lane, seg_pack<C>(px[i], lane));
-            if (bb && gray_px<C>(px[i]) != 0) { // pixels outside the rectangle are 0
-                const int y = P.dy0 + ly;
-                minx = minx < x ? minx : x;
-                maxx = maxx > x + 1 ? maxx : x + 1;
-                miny = miny < y ? miny : y;
-                maxy = maxy > y + 1 ? maxy : y + 1;
-            }
-        }
+        for (int i = 0; i < 4; i++)
+            px[i] = lx + i < P.dw ? warp_pixel<C, PERSP>(src, P, P.dx0 + lx + i, P.dy0 + ly) : 0u;
+        if (lx < P.dw) quad_store<C>(dst + (int64_t)ly * P.dpitch, lx, P.dw, px);
+        if (want_bbox) bbox_quad<C>(px, P.dx0 + lx, P.dy0 + ly, minx, miny, maxx, maxy);
     }
-    if (bb) bbox_block_accumulate(minx, miny, maxx, maxy, bb);
+    if (want_bbox) bbox_block_partial(minx, miny, maxx, maxy);
 }
 
 // host-side inverse exactly as cv::warpAffine / cv::warpPerspective compute it (double)
@@ -350,16 +379,19 @@ extern "C" int isx_warp(const uint8_t *src_dev, int sh, int sw, int c, int64_t s
     P.dx0 = dx0; P.dy0 = dy0; P.dw = dw; P.dh = dh;
     P.spitch = spitch; P.dpitch = dpitch;
     hipStream_t st = (hipStream_t)stream;
-    const int tiles_x = (dw + 63) / 64;
-    const int64_t n_tiles64 = (int64_t)tiles_x * ((dh + 15) / 16);
+    const int tiles_x = (dw + 255) / 256;
+    const int64_t n_tiles64 = (int64_t)tiles_x * ((dh + 3) / 4);
     ISX_REQUIRE(n_tiles64 < ((int64_t)1 << 31), "destination rectangle too large");
     const int n_tiles = (int)n_tiles64;
-    dim3 grid((unsigned)(n_tiles < 2048 ? n_tiles : 2048)), block(256);
+    const unsigned nblk = (unsigned)(n_tiles < ISX_BBOX_MAX_BLOCKS ? n_tiles : ISX_BBOX_MAX_BLOCKS);
+    dim3 grid(nblk), block(256);
     const bool persp = model == ISX_MODEL_HOMOGRAPHY;
-    if (c == 3 && persp) hipLaunchKernelGGL((warp_kernel<3, true>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, bbox_out_dev);
-    else if (c == 3) hipLaunchKernelGGL((warp_kernel<3, false>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, bbox_out_dev);
-    else if (persp) hipLaunchKernelGGL((warp_kernel<1, true>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, bbox_out_dev);
-    else hipLaunchKernelGGL((warp_kernel<1, false>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, bbox_out_dev);
+    const int wb = bbox_out_dev != nullptr;
+    if (c == 3 && persp) hipLaunchKernelGGL((warp_kernel<3, true>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, wb);
+    else if (c == 3) hipLaunchKernelGGL((warp_kernel<3, false>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, wb);
+    else if (persp) hipLaunchKernelGGL((warp_kernel<1, true>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, wb);
+    else hipLaunchKernelGGL((warp_kernel<1, false>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, wb);
+    if (wb) hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(256), 0, st, (int)nblk, bbox_out_dev);
     return isx_launch_status("warp_kernel");
 }
 
@@ -379,35 +411,37 @@ __global__ void __launch_bounds__(256) alpha_blend_kernel(const uint8_t *__restr
                                                           const uint8_t *ref, int64_t rpitch, uint8_t *out,
                                                           int64_t opitch, int h, int w, double contrib,
                                                           double one_minus) {
-    // tile = 64 pixels x 16 rows; wave wv takes rows wv, wv+4, wv+8, wv+12 (8 row segments in flight)
-    const int lane = threadIdx.x & 63;
-    const int xs = blockIdx.x * 64;
-    const int y0 = blockIdx.y * 16 + (threadIdx.x >> 6);
-    const int nb = min(64, w - xs) * C;
-    uint32_t d1[4], d2[4];
+    // tile = 256 pixels x 8 rows; wave wv takes rows wv and wv + 4
+    const int x = blockIdx.x * 256 + 4 * (threadIdx.x & 63);
+    const int y0 = blockIdx.y * 8 + (threadIdx.x >> 6);
+    if (x >= w) return;
+    uint32_t pa[2][4], pb[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int y = y0 + 4 * i;
-        d1[i] = y < h ? seg_load(warped + y * wpitch + (int64_t)xs * C, nb, lane) : 0u;
-        d2[i] = y < h ? seg_load(ref + y * rpitch + (int64_t)xs * C, nb, lane) : 0u;
+    for (int i = 0; i < 2; i++) {
+        const int y = y0 + 4 * i, yc = min(y, h - 1);
+        quad_load<C>(warped + yc * wpitch, x, w, pa[i]);
+        quad_load<C>(ref + yc * rpitch, x, w, pb[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 2; i++) {
         const int y = y0 + 4 * i;
-        if (y >= h) break; // wave-uniform
-        const uint32_t pa = seg_pixel<C>(d1[i], lane), pb = seg_pixel<C>(d2[i], lane);
-        const bool overlap = gray_px<C>(pa) > 10 && gray_px<C>(pb) > 10;
-        uint32_t po = 0;
+        if (y >= h) break;
+        uint32_t po[4];
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            int va = (pa >> (8 * c)) & 255, vb = (pb >> (8 * c)) & 255;
-            if (overlap) {
-                vb = (int)(contrib * (double)vb);
-                va = (int)(one_minus * (double)va);
+        for (int k = 0; k < 4; k++) {
+            const bool overlap = gray_px<C>(pa[i][k]) > 10 && gray_px<C>(pb[i][k]) > 10;
+            po[k] = 0;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                int va = (pa[i][k] >> (8 * c)) & 255, vb = (pb[i][k] >> (8 * c)) & 255;
+                if (overlap) {
+                    vb = (int)(contrib * (double)vb);
+                    va = (int)(one_minus * (double)va);
+                }
+                po[k] |= (uint32_t)((va + vb) & 255) << (8 * c);
             }
-            po |= (uint32_t)((va + vb) & 255) << (8 * c);
         }
-        seg_store(out + y * opitch + (int64_t)xs * C, nb, lane, seg_pack<C>(po, lane));
+        quad_store<C>(out + y * opitch, x, w, po);
     }
 }
 
@@ -421,7 +455,7 @@ extern "C" int isx_alpha_blend(const uint8_t *warped_dev, int64_t wpitch, const 
     const int64_t rb = (int64_t)w * c;
     ISX_REQUIRE(wpitch >= rb && rpitch >= rb && opitch >= rb, "pitch smaller than a row");
     const double one_minus = 1 - ref_contrib; // Python: (1-ref_image_contrib)
-    dim3 grid((w + 63) / 64, (h + 15) / 16), block(256);
+    dim3 grid((w + 255) / 256, (h + 7) / 8), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (c == 3)
         hipLaunchKernelGGL((alpha_blend_kernel<3>), grid, block, 0, st, warped_dev, wpitch, ref_dev, rpitch, out_dev, opitch, h, w, ref_contrib, one_minus);
@@ -458,23 +492,24 @@ __global__ void ext_init_kernel(int32_t *ext, int h, int w) {
 template <int C>
 __global__ void __launch_bounds__(256) row_extent_kernel(const uint8_t *__restrict__ warped, int64_t wpitch, int h,
                                                          int w, int32_t *__restrict__ ext) {
-    // one wave per (row, 1024-pixel span)
+    // one wave per (row, 1024-pixel span): 4 quads per lane
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (y >= h) return;
     int lo = INT_MAX, hi = -1;
     const uint8_t *row = warped + y * wpitch;
-#pragma unroll 8
-    for (int i = 0; i < 16; i++) {
-        const int xs = blockIdx.x * 1024 + i * 64;
-        if (xs < w) { // wave-uniform
-            const int nv = min(64, w - xs);
-            const uint32_t px = seg_pixel<C>(seg_load(row + (int64_t)xs * C, nv * C, lane), lane);
-            if (lane < nv && (px & 255u) != 0u) {
-                lo = lo < xs + lane ? lo : xs + lane;
-                hi = xs + lane;
+    uint32_t px[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) quad_load<C>(row, blockIdx.x * 1024 + i * 256 + 4 * lane, w, px[i]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int x = blockIdx.x * 1024 + i * 256 + 4 * lane;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((px[i][k] & 255u) != 0u) { // channel 0; pixels beyond w read as 0
+                lo = min(lo, x + k);
+                hi = max(hi, x + k);
             }
-        }
     }
     lo = wave_min(lo);
     hi = wave_max(hi);
@@ -487,28 +522,44 @@ __global__ void __launch_bounds__(256) row_extent_kernel(const uint8_t *__restri
 template <int C>
 __global__ void __launch_bounds__(256) col_extent_kernel(const uint8_t *__restrict__ warped, int64_t wpitch, int h,
                                                          int w, int32_t *__restrict__ ext) {
-    // wave = 64 adjacent columns x 32 rows (one coalesced row segment per step); lane owns a column
-    const int lane = threadIdx.x & 63;
-    const int xs = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
-    if (xs >= w) return; // wave-uniform
-    const int nv = min(64, w - xs), x = xs + lane;
-    const int ys = blockIdx.y * 32;
-    int lo = INT_MAX, hi = -1;
-#pragma unroll 8
-    for (int i = 0; i < 32; i++) {
-        const int y = ys + i;
-        if (y < h) {
-            const uint32_t px = seg_pixel<C>(seg_load(warped + y * wpitch + (int64_t)xs * C, nv * C, lane), lane);
-            const bool on = lane < nv && (px & 255u) != 0u && x != ext[y] && x != ext[h + y];
-            if (on) {
-                lo = lo < y ? lo : y;
-                hi = y;
-            }
+    // block = 256 columns x 32 rows; wave wv takes rows wv, wv+4, ... (8 row loads in flight, a lane owns 4
+    // adjacent columns); the four waves are merged through LDS: one atomic pair per column and block
+    __shared__ int slo[4][256], shi[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 256 + 4 * lane;
+    const int ys = blockIdx.y * 32 + wave;
+    int lo[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX}, hi[4] = {-1, -1, -1, -1};
+    if (x < w) {
+        uint32_t px[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int y = ys + 4 * i;
+            quad_load<C>(warped + (int64_t)min(y, h - 1) * wpitch, x, y < h ? w : 0, px[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int y = ys + 4 * i, yc = min(y, h - 1);
+            const int L = ext[yc], R = ext[h + yc];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((px[i][k] & 255u) != 0u && x + k != L && x + k != R) { // rows beyond h read as 0
+                    lo[k] = min(lo[k], y);
+                    hi[k] = max(hi[k], y);
+                }
         }
     }
-    if (hi >= 0) {
-        atomicMin(&ext[2 * h + x], lo);
-        atomicMax(&ext[2 * h + w + x], hi);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        slo[wave][4 * lane + k] = lo[k];
+        shi[wave][4 * lane + k] = hi[k];
+    }
+    __syncthreads();
+    const int col = threadIdx.x, xx = blockIdx.x * 256 + col;
+    const int l = min(min(slo[0][col], slo[1][col]), min(slo[2][col], slo[3][col]));
+    const int u = max(max(shi[0][col], shi[1][col]), max(shi[2][col], shi[3][col]));
+    if (xx < w && u >= 0) {
+        atomicMin(&ext[2 * h + xx], l);
+        atomicMax(&ext[2 * h + w + xx], u);
     }
 }
 
@@ -516,50 +567,58 @@ template <int C>
 __global__ void __launch_bounds__(256) gradient_blend_kernel(const uint8_t *__restrict__ warped, int64_t wpitch,
                                                              uint8_t *ref, int64_t rpitch, int h, int w, int feather,
                                                              const int32_t *__restrict__ ext) {
-    // tile = 64 pixels x 16 rows; wave wv takes rows wv, wv+4, wv+8, wv+12 (8 row segments in flight)
-    const int lane = threadIdx.x & 63;
-    const int xs = blockIdx.x * 64, x = xs + lane;
-    const int y0 = blockIdx.y * 16 + (threadIdx.x >> 6);
-    const int nv = min(64, w - xs);
-    uint32_t dw[4], dr[4];
+    // tile = 256 pixels x 8 rows; wave wv takes rows wv and wv + 4; a lane owns 4 adjacent pixels
+    const int x = blockIdx.x * 256 + 4 * (threadIdx.x & 63);
+    const int y0 = blockIdx.y * 8 + (threadIdx.x >> 6);
+    if (x >= w) return;
+    uint32_t pw[2][4], pr[2][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int y = y0 + 4 * i;
-        dw[i] = y < h ? seg_load(warped + y * wpitch + (int64_t)xs * C, nv * C, lane) : 0u;
-        dr[i] = y < h ? seg_load(ref + y * rpitch + (int64_t)xs * C, nv * C, lane) : 0u;
+    for (int i = 0; i < 2; i++) {
+        const int yc = min(y0 + 4 * i, h - 1);
+        quad_load<C>(warped + yc * wpitch, x, w, pw[i]);
+        quad_load<C>(ref + yc * rpitch, x, w, pr[i]);
     }
     const double f = (double)feather;
-    const int xc = x < w ? x : w - 1;
-    const int T = ext[2 * h + xc], B = ext[2 * h + w + xc];
+    int T[4], B[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int k = 0; k < 4; k++) {
+        const int xc = min(x + k, w - 1);
+        T[k] = ext[2 * h + xc];
+        B[k] = ext[2 * h + w + xc];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
         const int y = y0 + 4 * i;
-        if (y >= h) break; // wave-uniform
-        const uint32_t pw = seg_pixel<C>(dw[i], lane), pr = seg_pixel<C>(dr[i], lane);
-        // the factor chain is the same for every channel of the pixel; start from 1 and apply to mask=1 channels
-        double m = 1.0;
+        if (y >= h) break;
         const int L = ext[y], R = ext[h + y];
-        if (R >= 0) {
-            const int xe = L + feather < w ? L + feather : w;
-            if (x >= L && x < xe) m *= (double)(x - L) / f;
-            const int xb = R - feather > 0 ? R - feather : 0;
-            if (x >= xb && x <= R) m *= (double)(R - x) / f;
-        }
-        if (B >= 0) {
-            const int ye = T + feather < h ? T + feather : h;
-            if (y >= T && y < ye) m *= (double)(y - T) / f;
-            const int yb = B - feather > 0 ? B - feather : 0;
-            if (y >= yb && y <= B) m *= (double)(B - y) / f;
-        }
-        uint32_t po = 0;
+        uint32_t po[4];
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            const int wv = (pw >> (8 * c)) & 255, rv = (pr >> (8 * c)) & 255;
-            const double mk = wv > 0 ? m : 0.0;
-            const double r = (double)wv * mk + (double)rv * (1 - mk);
-            po |= (uint32_t)(uint8_t)(int)r << (8 * c);
+        for (int k = 0; k < 4; k++) {
+            const int xx = x + k;
+            // the factor chain is the same for every channel of the pixel; applied to the mask=1 channels
+            double m = 1.0;
+            if (R >= 0) {
+                const int xe = L + feather < w ? L + feather : w;
+                if (xx >= L && xx < xe) m *= (double)(xx - L) / f;
+                const int xb = R - feather > 0 ? R - feather : 0;
+                if (xx >= xb && xx <= R) m *= (double)(R - xx) / f;
+            }
+            if (B[k] >= 0) {
+                const int ye = T[k] + feather < h ? T[k] + feather : h;
+                if (y >= T[k] && y < ye) m *= (double)(y - T[k]) / f;
+                const int yb = B[k] - feather > 0 ? B[k] - feather : 0;
+                if (y >= yb && y <= B[k]) m *= (double)(B[k] - y) / f;
+            }
+            po[k] = 0;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const int wv = (pw[i][k] >> (8 * c)) & 255, rv = (pr[i][k] >> (8 * c)) & 255;
+                const double mk = wv > 0 ? m : 0.0;
+                const double r = (double)wv * mk + (double)rv * (1 - mk);
+                po[k] |= (uint32_t)(uint8_t)(int)r << (8 * c);
+            }
         }
-        seg_store(ref + y * rpitch + (int64_t)xs * C, nv * C, lane, seg_pack<C>(po, lane));
+        quad_store<C>(ref + y * rpitch, x, w, po);
     }
 }
 
@@ -574,7 +633,7 @@ extern "C" int isx_gradient_blend(const uint8_t *warped_dev, int64_t wpitch, uin
     hipStream_t st = (hipStream_t)stream;
     const int n = h > w ? h : w;
     hipLaunchKernelGGL(ext_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ext_dev, h, w);
-    dim3 gr((w + 1023) / 1024, (h + 3) / 4), gc((w + 255) / 256, (h + 31) / 32), gb((w + 63) / 64, (h + 15) / 16);
+    dim3 gr((w + 1023) / 1024, (h + 3) / 4), gc((w + 255) / 256, (h + 31) / 32), gb((w + 255) / 256, (h + 7) / 8);
     if (c == 3) {
         hipLaunchKernelGGL((row_extent_kernel<3>), gr, dim3(256), 0, st, warped_dev, wpitch, h, w, ext_dev);
         hipLaunchKernelGGL((col_extent_kernel<3>), gc, dim3(256), 0, st, warped_dev, wpitch, h, w, ext_dev);

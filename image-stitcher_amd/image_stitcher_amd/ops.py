@@ -410,6 +410,11 @@ def new_bbox(device):
     return bb
 
 
+def reset_bbox(bb):
+    check(_lib.lib().isx_bbox_reset(_ptr(bb), _stream()))
+    return bb
+
+
 def alpha_blend(warped, ref, contrib, out=None):
     """seamless_merge(image1=warped, image2=ref, contrib); out may be ref itself (in place)."""
     pw, h, w, c, wp = _img_args(warped, "warped")
@@ -424,14 +429,18 @@ def alpha_blend(warped, ref, contrib, out=None):
     return out
 
 
-def gradient_blend_roi(warped_roi, ref_roi, feather=10):
-    """ROI body of seamless_gradient_merge; ref_roi is updated in place."""
+def gradient_blend_roi(warped_roi, ref_roi, feather=10, ext=None):
+    """ROI body of seamless_gradient_merge; ref_roi is updated in place.  ext: optional int32 scratch of
+    2*h + 2*w elements (allocated when absent)."""
     pw, h, w, c, wp = _img_args(warped_roi, "warped_roi")
     pr, h2, w2, c2, rp = _img_args(ref_roi, "ref_roi")
     if (h, w, c) != (h2, w2, c2):
         raise IsxError("warped_roi and ref_roi differ in shape")
     with torch.cuda.device(ref_roi.device):
-        ext = torch.empty((2 * h + 2 * w,), dtype=torch.int32, device=ref_roi.device)
+        if ext is None:
+            ext = torch.empty((2 * h + 2 * w,), dtype=torch.int32, device=ref_roi.device)
+        elif ext.numel() < 2 * h + 2 * w or ext.dtype != torch.int32:
+            raise IsxError("ext scratch too small")
         check(_lib.lib().isx_gradient_blend(pw, wp, pr, rp, h, w, c, int(feather), _ptr(ext), _stream()))
     return ref_roi
 
