@@ -23,6 +23,14 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+#define ISX_B2 4194304 /* 1 << 22: count kernel's cin bias, keeps h in [2^20, 2^23) for valid rows; 0 = absent */
+#ifndef ISX_COUNT_WPS
+#define ISX_COUNT_WPS 3 /* waves per SIMD the count kernel is compiled for */
+#endif
+#ifndef ISX_KNN_DIAG
+#define ISX_KNN_DIAG 0 /* timing diagnostics, compile time only (tools/build_diag.sh); results are WRONG when != 0:
+                          1 no global loads, 4 no barriers, 8 no fold */
+#endif
 #define ISX_BIAS 6291456 /* 3 << 21 : keeps val = 2dot - nb' + BIAS in [32768, 2^23] */
 
 // ------------------------------------------------------------------------------------------------
@@ -34,6 +42,7 @@ __global__ void __launch_bounds__(256) desc_prep_kernel(const T *__restrict__ sr
                                                         int8_t *__restrict__ desc,
                                                         uint32_t *__restrict__ cbase,
                                                         int32_t *__restrict__ nrm,
+                                                        int32_t *__restrict__ cin,
                                                         int32_t *__restrict__ stats) {
     constexpr int DP = UPR * 16;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -82,6 +91,7 @@ __global__ void __launch_bounds__(256) desc_prep_kernel(const T *__restrict__ sr
     if (row < rows && unit == 0) {
         nrm[row] = sq_off;
         cbase[row] = (uint32_t)(ISX_BIAS - sq_off) << 8;
+        cin[row] = ISX_B2 - ((sq_off + 1) >> 1);
     }
     // stats: wave-level reduce then one atomic per wave
     int mx = row < rows ? sq_raw : 0;
@@ -107,31 +117,32 @@ extern "C" int isx_desc_pad(int d) {
 
 template <typename T>
 static int prep_launch(const void *src, int64_t rows, int d, int dp, int8_t *desc, uint32_t *cbase,
-                       int32_t *nrm, int32_t *stats, hipStream_t st) {
+                       int32_t *nrm, int32_t *cin, int32_t *stats, hipStream_t st) {
     const int upr = dp / 16;
     const int64_t threads = rows * upr;
     const unsigned grid = (unsigned)((threads + 255) / 256);
     if (upr == 2)
-        hipLaunchKernelGGL((desc_prep_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T *)src, rows, d, desc, cbase, nrm, stats);
+        hipLaunchKernelGGL((desc_prep_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T *)src, rows, d, desc, cbase, nrm, cin, stats);
     else if (upr == 4)
-        hipLaunchKernelGGL((desc_prep_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const T *)src, rows, d, desc, cbase, nrm, stats);
+        hipLaunchKernelGGL((desc_prep_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const T *)src, rows, d, desc, cbase, nrm, cin, stats);
     else
-        hipLaunchKernelGGL((desc_prep_kernel<T, 8>), dim3(grid), dim3(256), 0, st, (const T *)src, rows, d, desc, cbase, nrm, stats);
+        hipLaunchKernelGGL((desc_prep_kernel<T, 8>), dim3(grid), dim3(256), 0, st, (const T *)src, rows, d, desc, cbase, nrm, cin, stats);
     return isx_launch_status("desc_prep_kernel");
 }
 
 extern "C" int isx_desc_prep(const void *src_dev, int src_dtype, int64_t rows, int d, int8_t *desc_dev,
-                             uint32_t *cbase_dev, int32_t *nrm_dev, int32_t *stats_dev, void *stream) {
+                             uint32_t *cbase_dev, int32_t *nrm_dev, int32_t *cin_dev, int32_t *stats_dev,
+                             void *stream) {
     const int dp = isx_desc_pad(d);
     if (dp < 0) return dp;
     ISX_REQUIRE(rows >= 0 && rows < ((int64_t)1 << 31) / 8, "rows=%lld out of range", (long long)rows);
     ISX_REQUIRE(src_dtype == ISX_U8 || src_dtype == ISX_F32, "src_dtype must be ISX_U8 or ISX_F32");
     if (rows == 0) return ISX_OK;
-    ISX_REQUIRE(src_dev && desc_dev && cbase_dev && nrm_dev && stats_dev, "null device pointer");
+    ISX_REQUIRE(src_dev && desc_dev && cbase_dev && nrm_dev && cin_dev && stats_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (src_dtype == ISX_U8) return prep_launch<uint8_t>(src_dev, rows, d, dp, desc_dev, cbase_dev, nrm_dev, stats_dev, st);
-    return prep_launch<float>(src_dev, rows, d, dp, desc_dev, cbase_dev, nrm_dev, stats_dev, st);
+    if (src_dtype == ISX_U8) return prep_launch<uint8_t>(src_dev, rows, d, dp, desc_dev, cbase_dev, nrm_dev, cin_dev, stats_dev, st);
+    return prep_launch<float>(src_dev, rows, d, dp, desc_dev, cbase_dev, nrm_dev, cin_dev, stats_dev, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -345,10 +356,6 @@ extern "C" int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_d
     ISX_REQUIRE((idx_out_dev == nullptr) == (dist_out_dev == nullptr), "idx_out and dist_out must be given together");
     ISX_REQUIRE(idx_out_dev == nullptr || out_start_dev != nullptr, "out_start_dev is required with idx/dist outputs");
     if (n_items == 0 || max_nq == 0) return ISX_OK;
-    if (idx_out_dev == nullptr) {
-        ISX_REQUIRE(count_out_dev, "nothing to compute: idx/dist and count outputs are all NULL");
-        return isx_knn2_l2_count_items(desc_dev, nrm_dev, d_pad, items_dev, n_items, max_nq, ratio, count_out_dev, 0, stream);
-    }
     ISX_REQUIRE(desc_dev && cbase_dev && nrm_dev && items_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
     const int nqb = (max_nq + 255) / 256;
@@ -384,7 +391,6 @@ extern "C" int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_d
 // corners and only if they disagree (~1e-4 of the queries) the wave recomputes that query exactly
 // (v_dot4 over every train row).  The count is bit-identical to the index kernel's and the oracle's.
 // ------------------------------------------------------------------------------------------------
-#define ISX_B2 4194304 /* 1 << 22: keeps h in [2^20, 2^23) for every valid row; 0 = absent */
 
 __device__ __forceinline__ bool ratio_good(int s0, int s1, double ratio) {
     return (double)sqrtf((float)s0) < ratio * (double)sqrtf((float)s1);
@@ -432,16 +438,16 @@ __device__ __noinline__ void knn2_exact_scan(const int8_t *__restrict__ desc, co
 }
 
 template <int KS>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, ISX_COUNT_WPS)
 knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm,
-                  const isx_knn_item *__restrict__ items, int n_items, int nqb, double ratio,
+                  const int32_t *__restrict__ cin, const isx_knn_item *__restrict__ items, int n_items, int nqb, double ratio,
                   int32_t *__restrict__ count_out, int flags) {
     constexpr int DP = 32 * KS;
     constexpr int SLOTS = 2 * KS;
     constexpr int SH = (KS == 4) ? 1 : (KS == 2) ? 2 : 3;
     constexpr int CHUNK = 128;
     constexpr int BUF = CHUNK * DP + CHUNK * 4;
-    __shared__ __align__(16) unsigned char smem[2 * BUF];
+    __shared__ __align__(16) unsigned char smem[3 * BUF];
 
     const int id = blockIdx.x;
     const int xcd = id & 7;
@@ -474,51 +480,60 @@ unsigned m[2][8], G[2] = {0u, 0u};
         for (int r = 0; r < 8; r++) m[cb][r] = 0u;
 
     const int n_chunks = (nt + CHUNK - 1) / CHUNK;
-    v4i st[KS];
-    unsigned st_cin = 0;
 
-    auto load_chunk = [&](int c) {
+    // Staging by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write, no VALU address
+    // work; rows beyond nt are zero-filled by the buffer range check.  One instruction fills a 1 KiB piece
+    // of LDS linearly (lane i -> byte 16 i), so the XOR swizzle of the 16-byte slots is applied on the
+    // GLOBAL side: lane i fetches the slot that belongs at its LDS position.  Wave w stages pieces
+    // w, w+4, ... of a chunk; their swizzle phase is the same, so one per-lane offset serves them all.
+    const __amdgpu_buffer_rsrc_t rs_desc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(desc + (int64_t)it.t_start * DP), 0, nt * DP, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cin =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(cin + it.t_start), 0, nt * 4, 0x00020000);
+    constexpr int ROWS_PP = 1024 / DP;            // rows per 1 KiB piece
+    constexpr int PPW = (CHUNK * DP / 1024) / 4;  // pieces per wave and chunk
+    const int r_in = lane / SLOTS;
+    const int lane_voff = r_in * DP + (((lane % SLOTS) ^ (((wave * ROWS_PP + r_in) >> SH) & (SLOTS - 1))) << 4);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const unsigned smem_lds = (unsigned)(size_t)smem;
+    auto stage_chunk = [&](int c, int bufi) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-        for (int i = 0; i < KS; i++) {
-            const int u = tid + 256 * i;
-            const int row = u / SLOTS, slot = u % SLOTS;
-            const int jl = c * CHUNK + row;
-            st[i] = (jl < nt) ? *(const v4i *)(desc + (int64_t)(it.t_start + jl) * DP + slot * 16)
-                              : v4i{0, 0, 0, 0};
+        for (int k = 0; k < PPW; k++) {
+            const int piece = wv + 4 * k;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_desc, (lds_ptr_t)(smem_lds + bufi * BUF + piece * 1024), 16, lane_voff,
+                                                     c * (CHUNK * DP) + piece * 1024, 0, 0);
         }
-        if (tid < CHUNK) {
-            const int jl = c * CHUNK + tid;
-            st_cin = (jl < nt) ? (unsigned)(ISX_B2 - ((nrm[it.t_start + jl] + 1) >> 1)) : 0u;
-        }
+        if (wv < 2) // 128 cin values = 2 x 256 bytes
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cin, (lds_ptr_t)(smem_lds + bufi * BUF + CHUNK * DP + wv * 256), 4,
+                                                     lane * 4, c * (CHUNK * 4) + wv * 256, 0, 0);
     };
-    auto store_chunk = [&](int buf) {
-        unsigned char *base = smem + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < KS; i++) {
-            const int u = tid + 256 * i;
-            const int row = u / SLOTS, slot = u % SLOTS;
-            *(v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4)) = st[i];
-        }
-        if (tid < CHUNK) *(unsigned *)(base + CHUNK * DP + tid * 4) = st_cin;
-    };
-    // one 32-row tile against both query column blocks
-    auto mfma_tile = [&](const unsigned char *base, int tl, v16i (&acc)[2]) {
-        const int row = tl * 32 + col;
+#pragma clang diagnostic pop
+    // LDS fragments of one 32-row tile: the MFMA A operand (KS x 16 bytes of row `col`) and the 16 cin values
+    struct Frag {
         v4i a[KS];
+        v4i cv[4];
+    };
+    auto read_frag = [&](const unsigned char *base, int tl, Frag &f) {
+        const int row = tl * 32 + col;
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             const int slot = 2 * ks + h;
-            a[ks] = *(const v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4));
+            f.a[ks] = *(const v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4));
         }
-        v4i cv[4];
 #pragma unroll
-        for (int g = 0; g < 4; g++) cv[g] = *(const v4i *)(base + CHUNK * DP + (tl * 32 + 8 * g + 4 * h) * 4);
+        for (int g = 0; g < 4; g++) f.cv[g] = *(const v4i *)(base + CHUNK * DP + (tl * 32 + 8 * g + 4 * h) * 4);
+    };
+    // one 32-row tile against both query column blocks
+    auto mfma_tile = [&](const Frag &f, v16i (&acc)[2]) {
 #pragma unroll
         for (int cb = 0; cb < 2; cb++) {
-            v16i ac = {cv[0][0], cv[0][1], cv[0][2], cv[0][3], cv[1][0], cv[1][1], cv[1][2], cv[1][3],
-                       cv[2][0], cv[2][1], cv[2][2], cv[2][3], cv[3][0], cv[3][1], cv[3][2], cv[3][3]};
+            v16i ac = {f.cv[0][0], f.cv[0][1], f.cv[0][2], f.cv[0][3], f.cv[1][0], f.cv[1][1], f.cv[1][2], f.cv[1][3],
+                       f.cv[2][0], f.cv[2][1], f.cv[2][2], f.cv[2][3], f.cv[3][0], f.cv[3][1], f.cv[3][2], f.cv[3][3]};
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks], qf[cb][ks], ac, 0, 0, 0);
+            for (int ks = 0; ks < KS; ks++) ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[ks], qf[cb][ks], ac, 0, 0, 0);
             acc[cb] = ac;
         }
     };
@@ -543,33 +558,47 @@ unsigned m[2][8], G[2] = {0u, 0u};
         }
     };
 
-    if (n_chunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
-    }
+    // Three LDS buffers: chunk c+2 is staged while chunk c is consumed, so chunk c+1 is already visible
+    // (published by the previous barrier) and its first tile can be prefetched across the barrier.
+    if (n_chunks > 0) stage_chunk(0, 0);
+    if (n_chunks > 1) stage_chunk(1, 1);
     __syncthreads();
 
-    // software pipeline: the MFMAs of tile t+1 are issued before the fold of tile t, so that matrix and
-    // vector work of ONE wave overlap; accB is carried across the chunk boundary (zeros = absent rows)
+    // software pipeline: fragments of tile t+1 are read and the MFMAs of tile t+1 issued before the fold of
+    // tile t, so that LDS, matrix and vector work of ONE wave overlap; accB is carried across the chunk
+    // boundary (zeros = absent rows)
     v16i accA[2], accB[2];
 #pragma unroll
     for (int cb = 0; cb < 2; cb++) accB[cb] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    Frag f0, f1;
+    if (wave_live) read_frag(smem, 0, f0);
+    int buf = 0;
     for (int c = 0; c < n_chunks; c++) {
-        const int buf = c & 1;
-        if (c + 1 < n_chunks && !(flags & 256)) load_chunk(c + 1);
+        const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
+        if (c + 2 < n_chunks && !(ISX_KNN_DIAG & 1)) stage_chunk(c + 2, buf2); // last read before the previous barrier
         const unsigned char *base = smem + buf * BUF;
         if (wave_live) {
-            mfma_tile(base, 0, accA);
+            // the scheduling fences keep each step's live ranges inside the step (without them the
+            // scheduler hoists every LDS read to the top of the chunk and spills)
+            read_frag(base, 1, f1);
+            mfma_tile(f0, accA);
             fold_tile(accB);
-            mfma_tile(base, 1, accB);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(base, 2, f0);
+            mfma_tile(f1, accB);
             fold_tile(accA);
-            mfma_tile(base, 2, accA);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(base, 3, f1);
+            mfma_tile(f0, accA);
             fold_tile(accB);
-            mfma_tile(base, 3, accB);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(smem + buf1 * BUF, 0, f0); // published by the previous barrier (unused after the last chunk)
+            mfma_tile(f1, accB);
             fold_tile(accA);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (c + 1 < n_chunks && !(flags & 512)) store_chunk(buf ^ 1);
-        if (!(flags & 1024)) __syncthreads();
+        if (!(ISX_KNN_DIAG & 4)) __syncthreads();
+        buf = buf1;
     }
     if (!wave_live) return;
     fold_tile(accB);
@@ -606,7 +635,6 @@ unsigned m[2][8], G[2] = {0u, 0u};
                 amb = (g_best != g_worst) || (flags & 1);
             }
         }
-        if (flags & 2048) amb = false;
         unsigned long long am = __ballot(amb);
         while (am) {
             const int L = __ffsll((long long)am) - 1;
@@ -621,13 +649,13 @@ unsigned m[2][8], G[2] = {0u, 0u};
     if (lane == 0 && good_cnt) atomicAdd(&count_out[item_i], good_cnt);
 }
 
-extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, int d_pad,
-                                       const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
-                                       int32_t *count_out_dev, int flags, void *stream) {
+extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev,
+                                       int d_pad, const isx_knn_item *items_dev, int n_items, int max_nq,
+                                       double ratio, int32_t *count_out_dev, int flags, void *stream) {
     ISX_REQUIRE(d_pad == 32 || d_pad == 64 || d_pad == 128, "d_pad must be 32, 64 or 128 (got %d)", d_pad);
     ISX_REQUIRE(n_items >= 0 && max_nq >= 0, "negative size");
     if (n_items == 0 || max_nq == 0) return ISX_OK;
-    ISX_REQUIRE(desc_dev && nrm_dev && items_dev && count_out_dev, "null device pointer");
+    ISX_REQUIRE(desc_dev && nrm_dev && cin_dev && items_dev && count_out_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
     const int nqb = (max_nq + 255) / 256;
     const int64_t blocks = (int64_t)((n_items + 7) / 8) * 8 * nqb;
@@ -635,11 +663,11 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)blocks), block(256);
     if (d_pad == 128)
-        hipLaunchKernelGGL((knn2_count_kernel<4>), grid, block, 0, st, desc_dev, nrm_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
+        hipLaunchKernelGGL((knn2_count_kernel<4>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
     else if (d_pad == 64)
-        hipLaunchKernelGGL((knn2_count_kernel<2>), grid, block, 0, st, desc_dev, nrm_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
+        hipLaunchKernelGGL((knn2_count_kernel<2>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
     else
-        hipLaunchKernelGGL((knn2_count_kernel<1>), grid, block, 0, st, desc_dev, nrm_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
+        hipLaunchKernelGGL((knn2_count_kernel<1>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
     return isx_launch_status("knn2_count_kernel");
 }
 

@@ -4,7 +4,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libisx_hip.so")
+LIB_PATH = os.environ.get("ISX_LIB_PATH") or os.path.join(HERE, "lib", "libisx_hip.so")  # override: diagnostic builds only
 
 U8, F32 = 0, 1
 NORM_L2, NORM_HAMMING = 0, 1
@@ -20,11 +20,11 @@ SIGNATURES = {
     "isx_last_error": (ctypes.c_char_p, []),
     "isx_device_count": (c_int, []),
     "isx_desc_pad": (c_int, [c_int]),
-    "isx_desc_prep": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "isx_desc_prep": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isx_knn2_l2_items": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "isx_knn2_l2_count_items": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_void_p, c_int,
-                                        c_void_p]),
+    "isx_knn2_l2_count_items": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_void_p,
+                                        c_int, c_void_p]),
     "isx_knn2_hamming_items": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
     "isx_f32_norms": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),

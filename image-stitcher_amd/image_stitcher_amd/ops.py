@@ -26,8 +26,8 @@ class PreparedDescriptors:
     """Descriptors of one or more images, resident in HBM in the layout the matcher consumes
     (int8 value-128 rows padded to 32/64/128 bytes, per-row key bases and norms)."""
 
-    def __init__(self, desc, cbase, nrm, starts, counts, d, d_pad, max_norm2):
-        self.desc, self.cbase, self.nrm = desc, cbase, nrm
+    def __init__(self, desc, cbase, nrm, cin, starts, counts, d, d_pad, max_norm2):
+        self.desc, self.cbase, self.nrm, self.cin = desc, cbase, nrm, cin
         self.starts = np.asarray(starts, np.int64)  # first row of every image
         self.counts = np.asarray(counts, np.int64)  # rows of every image
         self.d, self.d_pad, self.max_norm2 = d, d_pad, max_norm2
@@ -87,9 +87,10 @@ def prepare_descriptor_tensor(src, starts, counts, check_range=True):
         desc = torch.empty((rows, d_pad), dtype=torch.int8, device=dev)
         cbase = torch.empty((rows,), dtype=torch.int32, device=dev)
         nrm = torch.empty((rows,), dtype=torch.int32, device=dev)
+        cin = torch.empty((rows,), dtype=torch.int32, device=dev)
         stats = torch.zeros((2,), dtype=torch.int32, device=dev)
         check(L.isx_desc_prep(_ptr(src), _lib.U8 if src.dtype == torch.uint8 else _lib.F32, rows, d,
-                              _ptr(desc), _ptr(cbase), _ptr(nrm), _ptr(stats), _stream()))
+                              _ptr(desc), _ptr(cbase), _ptr(nrm), _ptr(cin), _ptr(stats), _stream()))
         max_norm2 = None
         if check_range:
             s = stats.cpu().numpy()
@@ -100,7 +101,7 @@ def prepare_descriptor_tensor(src, starts, counts, check_range=True):
             if 2 * max_norm2 >= _lib.L2_EXACT_LIMIT:
                 raise IsxError(f"descriptor norms too large for the exact integer path "
                                f"(2*{max_norm2} >= {_lib.L2_EXACT_LIMIT})")
-    return PreparedDescriptors(desc, cbase, nrm, starts, counts, d, d_pad, max_norm2)
+    return PreparedDescriptors(desc, cbase, nrm, cin, starts, counts, d, d_pad, max_norm2)
 
 
 def order_items_for_xcd(items):
@@ -184,7 +185,7 @@ def knn2_l2_items(P, items, ratio, want_matches=False, xcd_order=True, plan=None
                                       max_nq, float(ratio), _ptr(idx), _ptr(dist), _ptr(out_dev),
                                       _ptr(counts), _stream()))
         else:  # count-only kernel (verify_all: test-hook flags of isx_knn2_l2_count_items)
-            check(L.isx_knn2_l2_count_items(_ptr(P.desc), _ptr(P.nrm), P.d_pad, _ptr(items_dev), m, max_nq,
+            check(L.isx_knn2_l2_count_items(_ptr(P.desc), _ptr(P.nrm), _ptr(P.cin), P.d_pad, _ptr(items_dev), m, max_nq,
                                             float(ratio), _ptr(counts), int(verify_all), _stream()))
         if events is not None:
             events[1].record()

@@ -60,12 +60,13 @@ int isx_desc_pad(int d);
  *   desc_dev  : rows x isx_desc_pad(d) int8   (value - 128, zero padded)
  *   cbase_dev : rows uint32                   ((BIAS - ||v-128||^2) << 8, the per-train-row key base)
  *   nrm_dev   : rows int32                    (||v-128||^2)
+ *   cin_dev   : rows int32                    (2^22 - ceil(nrm/2): MFMA start value of the count-only kernel)
  *   stats_dev : 2 int32, caller-zeroed: [0] |= 1 if a float value was not an integer in [0,255];
  *               [1] = max over rows of ||v||^2 (atomicMax) -- the caller checks 2*max < ISX_L2_EXACT_LIMIT
  */
 #define ISX_L2_EXACT_LIMIT 4197200 /* sqrtf is injective on integers below this (verified exhaustively) */
 int isx_desc_prep(const void *src_dev, int src_dtype, int64_t rows, int d, int8_t *desc_dev,
-                  uint32_t *cbase_dev, int32_t *nrm_dev, int32_t *stats_dev, void *stream);
+                  uint32_t *cbase_dev, int32_t *nrm_dev, int32_t *cin_dev, int32_t *stats_dev, void *stream);
 
 /* One matching work item: query rows [q_start, q_start+nq) against train rows [t_start, t_start+nt)
  * of the prepared arrays. */
@@ -78,7 +79,7 @@ typedef struct isx_knn_item {
  *   items_dev     : n_items work items (device)
  *   max_nq        : max over items of nq (host value; sizes the grid)
  *   ratio         : lowes_ratio_threshold, compared in float64 as the reference's Python does
- *   idx_out_dev   : optional (may be NULL) int32 [(out_start[e]+i)*2 + k], -1 = absent
+ *   idx_out_dev   : optional (NULL = counts only; prefer isx_knn2_l2_count_items then) int32 [(out_start[e]+i)*2 + k], -1 = absent
  *   dist_out_dev  : optional float32, same indexing (FLT_MAX where absent)
  *   out_start_dev : int64 per item, first output row of the item (required iff idx/dist given)
  *   count_out_dev : optional int32 per item, MUST be zeroed by the caller; receives len(good_matches)
@@ -90,12 +91,10 @@ int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_dev, const i
 
 /* Count-only form of the above: the loop body of ArbitraryStitcher.get_collections
  * (stitcher.py:292-296 uses only len(good_matches) of every ordered pair).  Same counts, bit for bit,
- * as isx_knn2_l2_items; it skips the train indices, which takes a third off the per-distance work.
- * isx_knn2_l2_items routes here by itself when idx_out_dev is NULL.
+ * as isx_knn2_l2_items; it skips the train indices, which more than halves the per-distance vector work.
  *   count_out_dev : int32 per item, MUST be zeroed by the caller
- *   flags         : bit 0 = decide EVERY query by the exact per-query scan (test hook, slow); bits >= 8
- *                   are timing diagnostics that give WRONG counts (tools/knn_variants.py), keep them 0 */
-int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, int d_pad,
+ *   flags         : bit 0 = decide EVERY query by the exact per-query scan (test hook, slow); other bits 0 */
+int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev, int d_pad,
                             const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
                             int32_t *count_out_dev, int flags, void *stream);
 

@@ -1,11 +1,12 @@
-"""Diagnostic: time the count kernel with debug flag variants (results are wrong for flags >= 256)."""
+"""Diagnostic: time the count kernel of the library named by ISX_LIB_PATH (default: the product build).
+Diagnostic builds (tools/build_diag.sh) give wrong counts by design."""
 import sys, os, time, ctypes
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "image-stitcher_amd"))
 import numpy as np, torch
 from image_stitcher_amd import ops, _lib
 from image_stitcher_amd.synthetic import overlapping_crops_descriptors
 n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-flag_list = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 256, 768, 1792]
+flag_list = [0]
 kp, d = 4096, 128
 des, _ = overlapping_crops_descriptors(seed=1, n_scenes=2, imgs_per_scene=n_img // 2, kp=kp, step=448, d=d)
 src = torch.from_numpy(des.reshape(-1, d)).cuda()
@@ -19,8 +20,8 @@ for fl in flag_list:
     for rep in range(3):
         counts = torch.zeros((m,), dtype=torch.int32, device=src.device)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        ops.check(L.isx_knn2_l2_count_items(ops._ptr(P.desc), ops._ptr(P.nrm), P.d_pad, ops._ptr(items_dev), m, kp, 0.65,
+        ops.check(L.isx_knn2_l2_count_items(ops._ptr(P.desc), ops._ptr(P.nrm), ops._ptr(P.cin), P.d_pad, ops._ptr(items_dev), m, kp, 0.65,
                                             ops._ptr(counts), fl, ops._stream()))
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     up = len(items) / 2
-    print(f"flags={fl:5d} {dt*1e3:.1f} ms {dt/up*1e6:.2f} us/pair {up/dt:.0f} pairs/s sum={int(counts.sum())}", flush=True)
+    print(f"lib={os.environ.get('ISX_LIB_PATH', 'product')[-24:]} {dt*1e3:.1f} ms {dt/up*1e6:.2f} us/pair {up/dt:.0f} pairs/s sum={int(counts.sum())}", flush=True)
