@@ -27,6 +27,17 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 #ifndef ISX_COUNT_WPS
 #define ISX_COUNT_WPS 3 /* waves per SIMD the count kernel is compiled for */
 #endif
+#ifndef ISX_COUNT_NCB
+#define ISX_COUNT_NCB 2 /* 32-query column blocks per wave of the count kernel (2 or 4) */
+#endif
+#ifndef ISX_STEP_FENCE
+#define ISX_STEP_FENCE __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef ISX_STEP_PATTERN /* experiment: force 1 MFMA : 5 VALU : 1 LDS read inside every step */
+#define ISX_SGB1 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#undef ISX_STEP_FENCE
+#define ISX_STEP_FENCE ISX_SGB1 ISX_SGB1 ISX_SGB1 ISX_SGB1 ISX_SGB1 ISX_SGB1 ISX_SGB1 ISX_SGB1 __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef ISX_KNN_DIAG
 #define ISX_KNN_DIAG 0 /* timing diagnostics, compile time only (tools/build_diag.sh); results are WRONG when != 0:
                           1 no global loads, 4 no barriers, 8 no fold */
@@ -456,28 +467,32 @@ knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ n
     const int item_i = (k / nqb) * 8 + xcd;
     if (item_i >= n_items) return;
     const isx_knn_item it = items[item_i];
-    if (qb * 256 >= it.nq) return;
+    constexpr int NCB = ISX_COUNT_NCB, NP = NCB / 2; // column blocks per wave, handled two at a time
+    constexpr int QPW = 32 * NCB, QPB = 4 * QPW;     // queries per wave / per workgroup
+    if (qb * QPB >= it.nq) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, col = lane & 31;
-    const int q0 = qb * 256 + wave * 64;
+    const int q0 = qb * QPB + wave * QPW;
     const int nt = it.nt;
     const bool wave_live = q0 < it.nq;
 
-    v4i qf[2][KS];
+    v4i qf[NCB][KS];
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++) {
+    for (int cb = 0; cb < NCB; cb++) {
         const int qi = q0 + cb * 32 + col;
         const v4i *p = (const v4i *)(desc + (int64_t)(it.q_start + (qi < it.nq ? qi : 0)) * DP);
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) qf[cb][ks] = (qi < it.nq) ? p[2 * ks + h] : v4i{0, 0, 0, 0};
     }
 
-unsigned m[2][8], G[2] = {0u, 0u};
+    unsigned m[NCB][8], G[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++)
+    for (int cb = 0; cb < NCB; cb++) {
+        G[cb] = 0u;
 #pragma unroll
         for (int r = 0; r < 8; r++) m[cb][r] = 0u;
+    }
 
     const int n_chunks = (nt + CHUNK - 1) / CHUNK;
 
@@ -526,25 +541,27 @@ unsigned m[2][8], G[2] = {0u, 0u};
 #pragma unroll
         for (int g = 0; g < 4; g++) f.cv[g] = *(const v4i *)(base + CHUNK * DP + (tl * 32 + 8 * g + 4 * h) * 4);
     };
-    // one 32-row tile against both query column blocks
-    auto mfma_tile = [&](const Frag &f, v16i (&acc)[2]) {
+    // one 32-row tile against the pair of query column blocks (2p, 2p+1)
+    auto mfma_tile = [&](const Frag &f, int p, v16i (&acc)[2]) {
 #pragma unroll
         for (int cb = 0; cb < 2; cb++) {
             v16i ac = {f.cv[0][0], f.cv[0][1], f.cv[0][2], f.cv[0][3], f.cv[1][0], f.cv[1][1], f.cv[1][2], f.cv[1][3],
                        f.cv[2][0], f.cv[2][1], f.cv[2][2], f.cv[2][3], f.cv[3][0], f.cv[3][1], f.cv[3][2], f.cv[3][3]};
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[ks], qf[cb][ks], ac, 0, 0, 0);
+            for (int ks = 0; ks < KS; ks++)
+                ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[ks], qf[2 * p + cb][ks], ac, 0, 0, 0);
             acc[cb] = ac;
         }
     };
     // fold one tile into the running stream maxima / runner-up (20 VALU ops per column block)
-    auto fold_tile = [&](const v16i (&acc)[2]) {
+    auto fold_tile = [&](const v16i (&acc)[2], int p) {
 #pragma unroll
-        for (int cb = 0; cb < 2; cb++) {
+        for (int c2 = 0; c2 < 2; c2++) {
+            const int cb = 2 * p + c2;
 #pragma unroll
             for (int r = 0; r < 8; r += 2) {
-                unsigned x0 = (unsigned)acc[cb][r], y0 = (unsigned)acc[cb][r + 8];
-                unsigned x1 = (unsigned)acc[cb][r + 1], y1 = (unsigned)acc[cb][r + 9];
+                unsigned x0 = (unsigned)acc[c2][r], y0 = (unsigned)acc[c2][r + 8];
+                unsigned x1 = (unsigned)acc[c2][r + 1], y1 = (unsigned)acc[c2][r + 9];
                 const unsigned t0 = umed3(m[cb][r], x0, y0);
                 const unsigned t1 = umed3(m[cb][r + 1], x1, y1);
                 // opaque re-definitions: keep the optimiser from sharing max(m, x) between the med3 and
@@ -580,32 +597,57 @@ unsigned m[2][8], G[2] = {0u, 0u};
         if (wave_live) {
             // the scheduling fences keep each step's live ranges inside the step (without them the
             // scheduler hoists every LDS read to the top of the chunk and spills)
-            read_frag(base, 1, f1);
-            mfma_tile(f0, accA);
-            fold_tile(accB);
-            __builtin_amdgcn_sched_barrier(0);
-            read_frag(base, 2, f0);
-            mfma_tile(f1, accB);
-            fold_tile(accA);
-            __builtin_amdgcn_sched_barrier(0);
-            read_frag(base, 3, f1);
-            mfma_tile(f0, accA);
-            fold_tile(accB);
-            __builtin_amdgcn_sched_barrier(0);
-            read_frag(smem + buf1 * BUF, 0, f0); // published by the previous barrier (unused after the last chunk)
-            mfma_tile(f1, accB);
-            fold_tile(accA);
-            __builtin_amdgcn_sched_barrier(0);
+            // unit u = (tile u / NP, column-block pair u % NP): accA on even units, accB on odd ones; the fold
+            // of unit u-1 runs under the MFMAs of unit u (the last unit of the previous chunk for u = 0)
+            if constexpr (NP == 1) {
+                read_frag(base, 1, f1);
+                mfma_tile(f0, 0, accA);
+                fold_tile(accB, 0);
+                ISX_STEP_FENCE;
+                read_frag(base, 2, f0);
+                mfma_tile(f1, 0, accB);
+                fold_tile(accA, 0);
+                ISX_STEP_FENCE;
+                read_frag(base, 3, f1);
+                mfma_tile(f0, 0, accA);
+                fold_tile(accB, 0);
+                ISX_STEP_FENCE;
+                read_frag(smem + buf1 * BUF, 0, f0); // published by the previous barrier (unused after the last chunk)
+                mfma_tile(f1, 0, accB);
+                fold_tile(accA, 0);
+                ISX_STEP_FENCE;
+            } else {
+#pragma unroll
+                for (int tl = 0; tl < 4; tl += 2) {
+                    read_frag(base, tl + 1, f1);
+                    mfma_tile(f0, 0, accA);
+                    fold_tile(accB, 1);
+                    ISX_STEP_FENCE;
+                    mfma_tile(f0, 1, accB);
+                    fold_tile(accA, 0);
+                    ISX_STEP_FENCE;
+                    if (tl == 0)
+                        read_frag(base, 2, f0);
+                    else
+                        read_frag(smem + buf1 * BUF, 0, f0); // published by the previous barrier
+                    mfma_tile(f1, 0, accA);
+                    fold_tile(accB, 1);
+                    ISX_STEP_FENCE;
+                    mfma_tile(f1, 1, accB);
+                    fold_tile(accA, 0);
+                    ISX_STEP_FENCE;
+                }
+            }
         }
         if (!(ISX_KNN_DIAG & 4)) __syncthreads();
         buf = buf1;
     }
     if (!wave_live) return;
-    fold_tile(accB);
+    fold_tile(accB, NP - 1);
 
     int good_cnt = 0;
 #pragma unroll
-    for (int cb = 0; cb < 2; cb++) {
+    for (int cb = 0; cb < NCB; cb++) {
         // two largest h of this lane's half of the train rows, then of the lane pair (col, 0|1)
         unsigned b1 = 0u, b2 = 0u;
 #pragma unroll
@@ -657,7 +699,8 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
     if (n_items == 0 || max_nq == 0) return ISX_OK;
     ISX_REQUIRE(desc_dev && nrm_dev && cin_dev && items_dev && count_out_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
-    const int nqb = (max_nq + 255) / 256;
+    const int qpb = 128 * ISX_COUNT_NCB; // queries per workgroup
+    const int nqb = (max_nq + qpb - 1) / qpb;
     const int64_t blocks = (int64_t)((n_items + 7) / 8) * 8 * nqb;
     ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
     hipStream_t st = (hipStream_t)stream;
