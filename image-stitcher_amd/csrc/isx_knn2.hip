@@ -67,15 +67,33 @@ __global__ void __launch_bounds__(256) desc_prep_kernel(const T *__restrict__ sr
     out.v = v4i{0, 0, 0, 0};
     if (row < rows) {
         const T *p = src + row * (int64_t)d;
+        // 16 source values of this unit in one or four 16-byte loads when the row layout allows it
+        union {
+            v4i v;
+            uint8_t b[16];
+        } in8;
+        union {
+            v4i v[4];
+            float f[16];
+        } in32;
+        const bool wide = (d & 15) == 0 && ((uintptr_t)src & 15) == 0; // then unit*16+16 <= d for every loaded unit
+        if (wide && unit * 16 < d) {
+            if constexpr (sizeof(T) == 1) {
+                in8.v = *(const v4i *)(p + unit * 16);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) in32.v[q] = *(const v4i *)(p + unit * 16 + 4 * q);
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int k = unit * 16 + e;
             int v = 128; // padding: offset value 0
             if (k < d) {
                 if constexpr (sizeof(T) == 1) {
-                    v = (int)p[k];
+                    v = wide ? (int)in8.b[e] : (int)p[k];
                 } else {
-                    const float f = (float)p[k];
+                    const float f = wide ? in32.f[e] : (float)p[k];
                     const int iv = (int)f;
                     if (!((float)iv == f) || iv < 0 || iv > 255) {
                         bad = 1;
