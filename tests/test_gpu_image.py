@@ -129,3 +129,29 @@ def test_gradient_blend_parity(cuda, orc, c):
         ops.gradient_blend_roi(wd[ry0:ry1, rx0:rx1], rd[ry0:ry1, rx0:rx1])
         got = rd.cpu().numpy()
         assert np.array_equal(got, exp), f"{(got != exp).sum()} differ"
+
+
+def test_large_images_exceed_the_capped_grids(cuda, orc):
+    """Images with more tiles than the capped (strided) grids of warp_kernel / bbox_nonzero_kernel and an
+    odd-offset view: exercises the tile loop, the per-block bbox table and the finish kernel."""
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(77)
+    big = np.zeros((3011, 4003, 3), np.uint8)
+    big[501:2777, 333:3901] = rand_img(rng, 2276, 3568, 3, 0, 256)
+    d = dev(big)
+    assert ops.bbox_to_corners(ops.bbox_nonzero(d).cpu().numpy()) == orc.bbox_nonzero(big)
+    view = d[7:3000, 13:3999]
+    assert ops.bbox_to_corners(ops.bbox_nonzero(view).cpu().numpy()) == orc.bbox_nonzero(np.ascontiguousarray(big[7:3000, 13:3999]))
+    # warp of a 1-channel frame into a large canvas rectangle (> 2048 tiles of 256 x 4)
+    img = _texture(rng, 700, 900, 1)
+    H, W = 2400, 3100
+    canvas = np.zeros((H, W), np.uint8)
+    ox, oy = 1001, 803
+    canvas[oy:oy + 700, ox:ox + 900] = img
+    th = np.deg2rad(3.0)
+    M = np.array([[1.05 * np.cos(th), -1.05 * np.sin(th), 40.5], [1.05 * np.sin(th), 1.05 * np.cos(th), -33.25]])
+    exp = orc.warp(canvas, M, (W, H), False)
+    bb = ops.new_bbox(cuda)
+    got = ops.warp(dev(img), M, False, (0, 0, W, H), src_xy=(ox, oy), bbox=bb).cpu().numpy()
+    assert np.array_equal(got, exp)
+    assert ops.bbox_to_corners(bb.cpu().numpy()) == orc.bbox_nonzero(exp)
