@@ -130,8 +130,10 @@ __global__ void __launch_bounds__(256) desc_prep_kernel(const T *__restrict__ sr
         mx = o > mx ? o : mx;
     }
     const unsigned long long anybad = __ballot(bad);
+    // (a plain read first: 260k same-address atomics, one per wave, serialise to ~2.7 ms on a 256 MiB set;
+    // almost every wave sees a maximum that is already recorded)
     if ((threadIdx.x & 63) == 0) {
-        if (mx > 0) atomicMax(&stats[1], mx);
+        if (mx > __atomic_load_n(&stats[1], __ATOMIC_RELAXED)) atomicMax(&stats[1], mx);
         if (anybad) atomicOr(&stats[0], 1);
     }
 }
