@@ -175,3 +175,65 @@ def test_matcher_routing_hamming_and_f32(cuda, orc, world):
     ridx, rdist = orc.knn2(f0, f1)
     got = m.dist.cpu().numpy()
     assert np.abs(got - rdist).max() <= 1e-4 * rdist.max()
+
+
+def test_stitch_collections_greedy_merge(cuda, orc, world, tmp_path):
+    """ArbitraryStitcher.stitch_collections (stitcher.py:306-374) on resident mosaics.  Every
+    Stitcher.stitch call of the greedy loop is recorded and replayed on the oracle pipeline: call order,
+    corner carry-over, None/tuple results, bit-exact mosaics given the same transform; one blend_i.png per
+    collection; the return value is [] as in the reference."""
+    from image_stitcher_amd import ArbitraryStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    from image_stitcher_amd.synthetic import crop_path
+    from PIL import Image
+    a = _frames(world, 3, seed=3)
+    b = crop_path(world, 2, (240, 320), seed=5, start=(1500.0, 400.0))[0]
+    order = [a[0], b[0], a[2], a[1], b[1]]  # two interleaved chains, the a-chain out of path order
+    det = NumpyOrbLite(nfeatures=500)
+    st = ArbitraryStitcher(images=list(order), with_tqdm=False, log_level=3, algorithm=1, detector=det,
+                           min_match_count=40, output_dir=str(tmp_path))
+    cols = st.get_collections()
+    assert sorted(map(sorted, cols)) == [[0, 2, 3], [1, 4]]
+    calls = []
+    inner = st.stitch
+
+    def recording_stitch(ref, img, tf=None, corners=None):
+        ref_h = np.array(np.asarray(ref))
+        res = inner(ref, img, tf=tf, corners=corners)
+        calls.append((ref_h, np.asarray(img), corners, res))
+        return res
+    st.stitch = recording_stitch
+    assert st.stitch_collections(cols) == []
+    cfg = Cfg(type=0, blender=1, ref_image_contrib=0.5, min_match_count=40)
+    # replay: the same greedy loop driven by the oracle pipeline must make the same calls in the same order
+    it = iter(calls)
+    finals = []
+    for coll in cols:
+        idxs = list(coll)
+        ref_img = np.asarray(order[idxs.pop(0)])
+        while idxs:
+            matched, corners, done = False, None, []
+            for k in idxs:
+                ref_h, img_h, c_in, res = next(it)
+                assert np.array_equal(ref_h, ref_img) and img_h is order[k] and c_in == corners
+                o = oracle_stitch(ref_img, order[k], det, cfg, corners=corners)
+                assert (o is None) == (res is None) and o is not False and res is not False
+                if res is None:
+                    corners = None
+                    continue
+                mosaic, corners, tf = res
+                o2 = oracle_stitch(ref_img, order[k], det, cfg, tf=(tf.M, tf.src_pts, tf.dst_pts), corners=c_in)
+                assert np.array_equal(tf.src_pts, o[2][1]) and np.array_equal(np.asarray(mosaic), o2[0]) and corners == o2[1]
+                ref_img = o2[0]
+                matched = True
+                done.append(k)
+            for k in done:
+                idxs.remove(k)
+            if not matched:
+                break
+        finals.append(ref_img)
+    assert next(it, None) is None
+    for i, f in enumerate(finals):
+        png = np.asarray(Image.open(tmp_path / f"blend_{i}.png"))
+        assert np.array_equal(png[..., ::-1] if png.ndim == 3 else png, f)
+        assert f.shape[1] > 320 * 1.1  # every collection really grew
