@@ -53,11 +53,12 @@ def components_from_counts(n, pairs, counts_ij, counts_ji, min_match_count, n_un
     return comps, dc
 
 
-def all_gather_descriptors(local_des, group=None):
-    """local_des: (n_local, kp, d) uint8 tensor (equal shapes on every rank).  Returns (n, kp, d)."""
+def all_gather_descriptors(local_des, group=None, always=False):
+    """local_des: (n_local, kp, d) uint8 tensor (equal shapes on every rank).  Returns (n, kp, d).
+    always=True issues the collective even in a world of one (used to exercise the RCCL path on one GPU)."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not always:
         return local_des
     # concatenated (not stacked) output shape: the form both RCCL and gloo accept
     out = torch.empty((world * local_des.shape[0],) + tuple(local_des.shape[1:]), dtype=local_des.dtype,
@@ -66,10 +67,10 @@ def all_gather_descriptors(local_des, group=None):
     return out
 
 
-def gather_counts(local_counts, n_pairs_total, rank, world, group=None):
+def gather_counts(local_counts, n_pairs_total, rank, world, group=None, always=False):
     """local_counts: (p_local, 2) int32 for pairs rank::world.  Rank 0 returns (n_pairs_total, 2); others None."""
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not always:
         return local_counts
     per = (n_pairs_total + world - 1) // world
     pad = torch.zeros((per, 2), dtype=torch.int32, device=local_counts.device)

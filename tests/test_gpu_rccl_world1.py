@@ -1,0 +1,40 @@
+"""The collectives of the sharded get_collections path issued through RCCL (backend "nccl") on device tensors
+of the shapes and dtypes bench.py uses, in a process group of one rank: checks that RCCL accepts the calls
+(uint8 all_gather_into_tensor with a concatenated output, int32 gather to rank 0) and returns the data
+unchanged.  The multi-rank arithmetic is covered on CPU by tests/test_dist_pairs_gloo.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_collectives_world_of_one(cuda):
+    import torch
+    import torch.distributed as dist
+    from image_stitcher_amd import pairs as prs
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(0)
+        local = torch.from_numpy(rng.integers(0, 256, (4, 512, 128), dtype=np.uint8)).to(dev)
+        full = prs.all_gather_descriptors(local, always=True)
+        assert full.shape == local.shape and torch.equal(full, local)
+        counts = torch.from_numpy(rng.integers(0, 4096, (37, 2)).astype(np.int32)).to(dev)
+        allc = prs.gather_counts(counts, 37, 0, 1, always=True)
+        assert allc.shape == (37, 2) and torch.equal(allc, counts)
+        dist.barrier()
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # bench.py's max-over-ranks timing
+        assert float(t.item()) == 1.5
+    finally:
+        dist.destroy_process_group()
