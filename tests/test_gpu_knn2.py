@@ -161,3 +161,19 @@ def test_count_kernel_ratio_boundary_parity_bit(cuda, orc):
     _count_case(orc, des[:12], 0.5, False)
     _count_case(orc, [des[0]] + des[12:22], 0.5, False)
     _count_case(orc, [des[0]] + des[22:], 0.5, False)
+
+
+@pytest.mark.parametrize("nq,nt,d", [(96, 70001, 32), (70001, 33, 32), (40, 20000, 128)])
+def test_long_train_and_query_sets(cuda, orc, nq, nt, d):
+    """Sizes past every internal period: > 2^16 train rows (index packing, 512-row segments, many LDS
+    chunks) and > 2^16 queries (grid y / query-block arithmetic), with duplicates planted far apart."""
+    rng = np.random.default_rng(nq + nt)
+    hi = 256 if d == 32 else 170
+    q = rng.integers(0, hi, (nq, d), dtype=np.uint8)
+    t = rng.integers(0, hi, (nt, d), dtype=np.uint8)
+    if nt > 1000:
+        t[nt - 1] = t[5]            # equal distances 70k rows apart: the lower index must win both slots
+        t[nt // 2] = q[3]           # exact match in the middle
+        q[7] = t[5]
+    _check_pair(orc, q, t)
+    _count_case(orc, [q, t], 0.8, False)
