@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .async_save import AsyncImageWriter, write_image
 from .detect import make_detector
 from .device_image import DeviceImage
 from .pairs import components_from_counts, directed_items, gather_counts, shard_pairs, unordered_pairs
@@ -109,7 +110,7 @@ class Stitcher:
                  blend_processor=lambda x: x,
                  blender=1,
                  ref_image_contrib=0.5,  # Used in alpha blending
-                 *, detector=None, device=None, resident=True, norm="l2"):
+                 *, detector=None, device=None, resident=True, norm="l2", async_save=False):
         options = {
             "log_level": [logging.DEBUG, logging.INFO, logging.WARNING],
             "algorithm": ["sift", "orb", "akaze"],
@@ -151,6 +152,10 @@ class Stitcher:
         if norm not in ("l2", "hamming"):
             raise ValueError("norm must be 'l2' (what the reference's cv2.BFMatcher() computes) or 'hamming'")
         self.norm = norm  # extension: 'hamming' = cv2.BFMatcher(cv2.NORM_HAMMING) for binary descriptors
+        # extension: blend_N.png is copied out and encoded off the stitching stream (async_save.py); the
+        # file is on disk after flush_saves() (also run at interpreter exit), not when save_* returns
+        self.async_save = async_save
+        self._writer = None
 
     # ---- plumbing -------------------------------------------------------------------------------
     @property
@@ -253,18 +258,23 @@ class Stitcher:
 
     @timer
     def save_last_stitch(self, stitch, filename):
+        filepath = os.path.join(self.output_dir, filename)
+        if self.async_save:
+            if self._writer is None:
+                self._writer = AsyncImageWriter(self._dev())
+            self._writer.submit(stitch, filepath, self.blend_processor)
+            self.logger.info(f"Queued last stitch for {filepath}")
+            return
         processed = self.blend_processor(np.asarray(stitch))
         if not os.path.exists(self.output_dir):
             os.makedirs(self.output_dir)
-        filepath = os.path.join(self.output_dir, filename)
-        try:
-            import cv2
-            cv2.imwrite(filepath, processed)
-        except ImportError:
-            from PIL import Image
-            a = np.asarray(processed)
-            Image.fromarray(a[..., ::-1] if a.ndim == 3 else a).save(filepath)
+        write_image(filepath, processed)
         self.logger.info(f"Saved last stitch to {filepath}")
+
+    def flush_saves(self):
+        """Returns when every file queued by an async_save stitcher is on disk (no-op otherwise)."""
+        if self._writer is not None:
+            self._writer.flush()
 
     # ---- per-pair pipeline (stitcher.py:176-229) ------------------------------------------------------
     @staticmethod

@@ -237,3 +237,36 @@ def test_stitch_collections_greedy_merge(cuda, orc, world, tmp_path):
         png = np.asarray(Image.open(tmp_path / f"blend_{i}.png"))
         assert np.array_equal(png[..., ::-1] if png.ndim == 3 else png, f)
         assert f.shape[1] > 320 * 1.1  # every collection really grew
+
+
+def test_async_save_writes_the_same_files(cuda, world, tmp_path):
+    """async_save=True copies and encodes blend_N.png off the stitching stream; after
+    flush_saves() the files are identical to the synchronous stitcher's, in the same order, and the
+    stitching results themselves are unchanged."""
+    from image_stitcher_amd import ConsecutiveStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    from image_stitcher_amd.synthetic import procedural_world
+    from PIL import Image
+    frames = _frames(world, 5)
+    other = procedural_world(seed=99, h=240, w=320)
+    seq = frames[:3] + [other] + frames[3:]          # the unrelated frame forces a save_and_reset in mid-stream
+    outs = {}
+    for mode in (False, True):
+        d = tmp_path / ("async" if mode else "sync")
+        st = ConsecutiveStitcher(log_level=3, output_dir=str(d), consecutive_range=1, algorithm=1, min_match_count=40,
+                                 detector=NumpyOrbLite(nfeatures=500), backup_interval=1, async_save=mode,
+                                 blend_processor=lambda a: a[::-1].copy())
+        mosaics = []
+        for f in seq:
+            st.stitch_consecutive(f)
+            mosaics.append(None if st.refs[-1] is None else np.array(np.asarray(st.refs[-1])))
+        st.save_and_reset()
+        st.flush_saves()
+        files = sorted(p.name for p in d.iterdir())
+        outs[mode] = (files, {n: np.asarray(Image.open(d / n)) for n in files}, mosaics, st.stitch_count)
+    assert outs[False][0] == outs[True][0] and len(outs[True][0]) >= 2
+    for n in outs[False][0]:
+        assert np.array_equal(outs[False][1][n], outs[True][1][n]), n
+    assert outs[False][3] == outs[True][3]
+    for a, b in zip(outs[False][2], outs[True][2]):
+        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
