@@ -239,6 +239,8 @@ extern "C" int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int
 // ------------------------------------------------------------------------------------------------
 struct WarpParams {
     float m[9];
+    double im[9]; // the inverse map in double (classic arithmetic)
+    int bw0;      // classic perspective: width of the invoker's column blocks on the full canvas
     int src_x, src_y, sh, sw;
     int dx0, dy0, dw, dh;
     int64_t spitch, dpitch;
@@ -307,9 +309,65 @@ __device__ __forceinline__ uint32_t warp_pixel(const uint8_t *__restrict__ src, 
     return px;
 }
 
+// The classic arithmetic of OpenCV <= 4.10 (imgwarp.cpp WarpAffineInvoker / WarpPerspectiveInvoker +
+// remapBilinear with FixedPtCast<int, uchar, 15>), restated in oracle/orc_image.c warp_classic(): source
+// coordinates in 1/32 px fixed point from the double inverse map, int16 bilinear weights that sum to 32768
+// (entry (0,0) = {32767, 0, 0, 1}), value = (sum + 16384) >> 15.  Selected with ISX_WARP_CLASSIC.
+template <int C, bool PERSP>
+__device__ __forceinline__ uint32_t warp_pixel_classic(const uint8_t *__restrict__ src, const WarpParams &P, int x, int y) {
+    int X, Y;
+    if (!PERSP) {
+        const int X0 = __double2int_rn((P.im[1] * (double)y + P.im[2]) * 1024.0) + 16;
+        const int Y0 = __double2int_rn((P.im[4] * (double)y + P.im[5]) * 1024.0) + 16;
+        X = (X0 + __double2int_rn(P.im[0] * (double)x * 1024.0)) >> 5;
+        Y = (Y0 + __double2int_rn(P.im[3] * (double)x * 1024.0)) >> 5;
+    } else {
+        const int xb = x - x % P.bw0, x1 = x - xb;
+        const double X0 = P.im[0] * (double)xb + P.im[1] * (double)y + P.im[2];
+        const double Y0 = P.im[3] * (double)xb + P.im[4] * (double)y + P.im[5];
+        const double W0 = P.im[6] * (double)xb + P.im[7] * (double)y + P.im[8];
+        double W = W0 + P.im[6] * (double)x1;
+        W = W != 0.0 ? 32.0 / W : 0.0;
+        double fX = (X0 + P.im[0] * (double)x1) * W, fY = (Y0 + P.im[3] * (double)x1) * W;
+        // std::max(INT_MIN, std::min(INT_MAX, v)): a NaN ends at INT_MAX
+        fX = !(fX < 2147483647.0) ? 2147483647.0 : fX;
+        fX = fX < -2147483648.0 ? -2147483648.0 : fX;
+        fY = !(fY < 2147483647.0) ? 2147483647.0 : fY;
+        fY = fY < -2147483648.0 ? -2147483648.0 : fY;
+        X = __double2int_rn(fX);
+        Y = __double2int_rn(fY);
+    }
+    int ix = X >> 5, iy = Y >> 5;
+    ix = ix < -32768 ? -32768 : (ix > 32767 ? 32767 : ix);
+    iy = iy < -32768 ? -32768 : (iy > 32767 ? 32767 : iy);
+    const int fx = X & 31, fy = Y & 31;
+    int w00 = (32 - fy) * (32 - fx) * 32, w11 = fy * fx * 32;
+    const int w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32;
+    if ((fx | fy) == 0) {
+        w00 = 32767;
+        w11 = 1;
+    }
+    ix -= P.src_x; // frame coordinates: taps outside the frame are the zero padding / border
+    iy -= P.src_y;
+    const bool x0ok = (unsigned)ix < (unsigned)P.sw, x1ok = (unsigned)(ix + 1) < (unsigned)P.sw;
+    const bool y0ok = (unsigned)iy < (unsigned)P.sh, y1ok = (unsigned)(iy + 1) < (unsigned)P.sh;
+    if (!((x0ok || x1ok) && (y0ok || y1ok))) return 0u;
+    const uint8_t *r0 = src + (int64_t)iy * P.spitch + (int64_t)ix * C;
+    const uint8_t *r1 = r0 + P.spitch;
+    uint32_t px = 0;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int p00 = (x0ok && y0ok) ? r0[c] : 0, p01 = (x1ok && y0ok) ? r0[C + c] : 0;
+        const int p10 = (x0ok && y1ok) ? r1[c] : 0, p11 = (x1ok && y1ok) ? r1[C + c] : 0;
+        const int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + 16384) >> 15;
+        px |= (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * c);
+    }
+    return px;
+}
+
 // Tile = 256 pixels x 4 rows (one row per wave, a lane produces 4 adjacent pixels: eight gathers in
 // flight per lane, one 12-byte store).  Capped, strided grid; per-block partial bbox (see above).
-template <int C, bool PERSP>
+template <int C, bool PERSP, bool CLASSIC = false>
 __global__ void __launch_bounds__(256) warp_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
                                                    const WarpParams P, int tiles_x, int n_tiles, int want_bbox) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -321,7 +379,9 @@ __global__ void __launch_bounds__(256) warp_kernel(const uint8_t *__restrict__ s
         uint32_t px[4];
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            px[i] = lx + i < P.dw ? warp_pixel<C, PERSP>(src, P, P.dx0 + lx + i, P.dy0 + ly) : 0u;
+            px[i] = lx + i >= P.dw ? 0u
+                    : CLASSIC  ? warp_pixel_classic<C, PERSP>(src, P, P.dx0 + lx + i, P.dy0 + ly)
+                               : warp_pixel<C, PERSP>(src, P, P.dx0 + lx + i, P.dy0 + ly);
         if (lx < P.dw) quad_store<C>(dst + (int64_t)ly * P.dpitch, lx, P.dw, px);
         if (want_bbox) bbox_quad<C>(px, P.dx0 + lx, P.dy0 + ly, minx, miny, maxx, maxy);
     }
@@ -358,11 +418,13 @@ static void invert_3x3_cv(const double *m, double *o) {
     o[8] = (m[0] * m[4] - m[1] * m[3]) * d;
 }
 
-extern "C" int isx_warp(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
-                        const double *M_host, int model, uint8_t *dst_dev, int64_t dpitch, int dx0, int dy0,
-                        int dw, int dh, int32_t *bbox_out_dev, void *stream) {
+extern "C" int isx_warp_arith(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
+                              const double *M_host, int model, uint8_t *dst_dev, int64_t dpitch, int dx0, int dy0,
+                              int dw, int dh, int arith, int canvas_w, int canvas_h, int32_t *bbox_out_dev,
+                              void *stream) {
     ISX_REQUIRE(c == 1 || c == 3, "channels must be 1 or 3 (got %d)", c);
     ISX_REQUIRE(model == ISX_MODEL_AFFINE_PARTIAL || model == ISX_MODEL_HOMOGRAPHY, "bad model %d", model);
+    ISX_REQUIRE(arith == ISX_WARP_LINEAR_F32 || arith == ISX_WARP_CLASSIC, "bad warp arithmetic %d", arith);
     ISX_REQUIRE(M_host, "null M_host");
     ISX_REQUIRE(sh > 0 && sw > 0 && spitch >= (int64_t)sw * c, "bad source geometry");
     ISX_REQUIRE(dw >= 0 && dh >= 0 && dpitch >= (int64_t)dw * c, "bad destination geometry");
@@ -374,7 +436,15 @@ extern "C" int isx_warp(const uint8_t *src_dev, int sh, int sw, int c, int64_t s
         invert_3x3_cv(M_host, iM);
     else
         invert_affine_cv(M_host, iM);
-    for (int i = 0; i < 9; i++) P.m[i] = (float)iM[i];
+    for (int i = 0; i < 9; i++) P.m[i] = (float)iM[i], P.im[i] = iM[i];
+    P.bw0 = 64;
+    if (arith == ISX_WARP_CLASSIC && model == ISX_MODEL_HOMOGRAPHY) {
+        // WarpPerspectiveInvoker's blocks on the FULL destination of the reference's call (the canvas)
+        ISX_REQUIRE(canvas_w >= dx0 + dw && canvas_h >= dy0 + dh && dx0 >= 0 && dy0 >= 0,
+                    "classic perspective warp needs the size of the full canvas (got %dx%d)", canvas_w, canvas_h);
+        const int bh0 = canvas_h < 16 ? canvas_h : 16;
+        P.bw0 = 1024 / bh0 < canvas_w ? 1024 / bh0 : canvas_w;
+    }
     P.src_x = src_x; P.src_y = src_y; P.sh = sh; P.sw = sw;
     P.dx0 = dx0; P.dy0 = dy0; P.dw = dw; P.dh = dh;
     P.spitch = spitch; P.dpitch = dpitch;
@@ -387,12 +457,29 @@ extern "C" int isx_warp(const uint8_t *src_dev, int sh, int sw, int c, int64_t s
     dim3 grid(nblk), block(256);
     const bool persp = model == ISX_MODEL_HOMOGRAPHY;
     const int wb = bbox_out_dev != nullptr;
-    if (c == 3 && persp) hipLaunchKernelGGL((warp_kernel<3, true>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, wb);
-    else if (c == 3) hipLaunchKernelGGL((warp_kernel<3, false>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, wb);
-    else if (persp) hipLaunchKernelGGL((warp_kernel<1, true>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, wb);
-    else hipLaunchKernelGGL((warp_kernel<1, false>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, wb);
+#define ISX_WARP_LAUNCH(CC, PP, AA) \
+    hipLaunchKernelGGL((warp_kernel<CC, PP, AA>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, wb)
+    if (arith == ISX_WARP_CLASSIC) {
+        if (c == 3 && persp) ISX_WARP_LAUNCH(3, true, true);
+        else if (c == 3) ISX_WARP_LAUNCH(3, false, true);
+        else if (persp) ISX_WARP_LAUNCH(1, true, true);
+        else ISX_WARP_LAUNCH(1, false, true);
+    } else {
+        if (c == 3 && persp) ISX_WARP_LAUNCH(3, true, false);
+        else if (c == 3) ISX_WARP_LAUNCH(3, false, false);
+        else if (persp) ISX_WARP_LAUNCH(1, true, false);
+        else ISX_WARP_LAUNCH(1, false, false);
+    }
+#undef ISX_WARP_LAUNCH
     if (wb) hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(256), 0, st, (int)nblk, bbox_out_dev);
     return isx_launch_status("warp_kernel");
+}
+
+extern "C" int isx_warp(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
+                        const double *M_host, int model, uint8_t *dst_dev, int64_t dpitch, int dx0, int dy0,
+                        int dw, int dh, int32_t *bbox_out_dev, void *stream) {
+    return isx_warp_arith(src_dev, sh, sw, c, spitch, src_x, src_y, M_host, model, dst_dev, dpitch, dx0, dy0, dw, dh,
+                          ISX_WARP_LINEAR_F32, 0, 0, bbox_out_dev, stream);
 }
 
 extern "C" int isx_bbox_reset(int32_t *bbox_dev, void *stream) {

@@ -8,6 +8,7 @@ LIB_PATH = os.environ.get("ISX_LIB_PATH") or os.path.join(HERE, "lib", "libisx_h
 
 U8, F32 = 0, 1
 NORM_L2, NORM_HAMMING = 0, 1
+WARP_LINEAR_F32, WARP_CLASSIC = 0, 1  # enum isx_warp_arith
 MODEL_AFFINE_PARTIAL, MODEL_HOMOGRAPHY = 0, 1
 BLEND_ALPHA, BLEND_GRADIENT = 0, 1
 L2_EXACT_LIMIT = 4197200
@@ -35,6 +36,8 @@ SIGNATURES = {
     "isx_bbox_reset": (c_int, [c_void_p, c_void_p]),
     "isx_warp": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64,
                          c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isx_warp_arith": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64,
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isx_alpha_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                 c_double, c_void_p]),
     "isx_gradient_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,

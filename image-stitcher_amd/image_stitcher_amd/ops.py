@@ -382,10 +382,16 @@ def bbox_to_corners(bb_host):
     return ((int(bb_host[0]), int(bb_host[1])), (int(bb_host[2]), int(bb_host[3])))
 
 
-def warp(src, M, perspective, dst_rect, src_xy=(0, 0), out=None, bbox=None):
+WARP_ARITH = {"f32": _lib.WARP_LINEAR_F32, "classic": _lib.WARP_CLASSIC}
+
+
+def warp(src, M, perspective, dst_rect, src_xy=(0, 0), out=None, bbox=None, arith="f32", canvas=None):
     """cv2.warpAffine / cv2.warpPerspective (INTER_LINEAR, constant 0) of `src` placed at src_xy of a
     virtual canvas, producing canvas rectangle dst_rect = (x0, y0, w, h).  M: forward 2x3 / 3x3 float64.
-    bbox: optional int32[5] accumulator tensor (gray != 0 bbox of the produced pixels)."""
+    bbox: optional int32[5] accumulator tensor (gray != 0 bbox of the produced pixels).
+    arith: "f32" = OpenCV 4.11's float32 linear kernels (the reference's pinned version), "classic" = the
+    1/32-px fixed-point remap of OpenCV <= 4.10; canvas = (W, H) of the full destination, needed by the
+    classic perspective path (defaults to the extent of dst_rect)."""
     p, sh, sw, c, spitch = _img_args(src, "src")
     x0, y0, dw, dh = (int(v) for v in dst_rect)
     M = np.ascontiguousarray(M, np.float64)
@@ -397,10 +403,14 @@ def warp(src, M, perspective, dst_rect, src_xy=(0, 0), out=None, bbox=None):
         po, oh, ow, oc, opitch = _img_args(out, "out")
         if (oh, ow, oc) != (dh, dw, c):
             raise IsxError("out does not match dst_rect")
-        check(_lib.lib().isx_warp(p, sh, sw, c, spitch, int(src_xy[0]), int(src_xy[1]),
-                                  M.ctypes.data_as(ctypes.c_void_p),
-                                  _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL,
-                                  po, opitch, x0, y0, dw, dh, _ptr(bbox), _stream()))
+        if arith not in WARP_ARITH:
+            raise IsxError(f"arith must be one of {sorted(WARP_ARITH)}")
+        cw, ch = canvas if canvas is not None else (x0 + dw, y0 + dh)
+        check(_lib.lib().isx_warp_arith(p, sh, sw, c, spitch, int(src_xy[0]), int(src_xy[1]),
+                                        M.ctypes.data_as(ctypes.c_void_p),
+                                        _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL,
+                                        po, opitch, x0, y0, dw, dh, WARP_ARITH[arith], int(cw), int(ch),
+                                        _ptr(bbox), _stream()))
     return out
 
 

@@ -110,7 +110,7 @@ class Stitcher:
                  blend_processor=lambda x: x,
                  blender=1,
                  ref_image_contrib=0.5,  # Used in alpha blending
-                 *, detector=None, device=None, resident=True, norm="l2", async_save=False):
+                 *, detector=None, device=None, resident=True, norm="l2", async_save=False, warp_arith="f32"):
         options = {
             "log_level": [logging.DEBUG, logging.INFO, logging.WARNING],
             "algorithm": ["sift", "orb", "akaze"],
@@ -155,6 +155,11 @@ class Stitcher:
         # extension: blend_N.png is copied out and encoded off the stitching stream (async_save.py); the
         # file is on disk after flush_saves() (also run at interpreter exit), not when save_* returns
         self.async_save = async_save
+        # extension: which INTER_LINEAR arithmetic cv2.warp* is taken to run -- "f32" (OpenCV 4.11, the
+        # reference's pinned version) or "classic" (<= 4.10 fixed point); see ops.warp
+        if warp_arith not in ops.WARP_ARITH:
+            raise ValueError("warp_arith must be 'f32' or 'classic'")
+        self.warp_arith = warp_arith
         self._writer = None
 
     # ---- plumbing -------------------------------------------------------------------------------
@@ -385,7 +390,8 @@ class Stitcher:
             shape_c = (C,) if img_d.ndim == 3 else ()
             wbuf = torch.empty((qh, qw) + shape_c, dtype=torch.uint8, device=dev)
             wbb = ops.new_bbox(dev)
-            ops.warp(img_d.t, M, self.type == 1, (qx0, qy0, qw, qh), src_xy=(ox, oy), out=wbuf, bbox=wbb)
+            ops.warp(img_d.t, M, self.type == 1, (qx0, qy0, qw, qh), src_xy=(ox, oy), out=wbuf, bbox=wbb,
+                     arith=self.warp_arith, canvas=(W, H))
             wbb_h = wbb.cpu().numpy()
             wcorners = ops.bbox_to_corners(wbb_h)
 

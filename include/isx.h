@@ -36,6 +36,10 @@ enum isx_status {
 enum isx_dtype { ISX_U8 = 0, ISX_F32 = 1 };
 enum isx_norm { ISX_NORM_L2 = 0, ISX_NORM_HAMMING = 1 };
 enum isx_model { ISX_MODEL_AFFINE_PARTIAL = 0, ISX_MODEL_HOMOGRAPHY = 1 }; /* stitcher.py:137-140 `type` */
+/* which INTER_LINEAR arithmetic cv2.warpAffine / cv2.warpPerspective is taken to run:
+ * the float32 linear kernels of OpenCV 4.11 (the reference's pinned opencv-python==4.11.0.86,
+ * requirements.txt:6) or the classic 1/32-px fixed-point remap of OpenCV <= 4.10 */
+enum isx_warp_arith { ISX_WARP_LINEAR_F32 = 0, ISX_WARP_CLASSIC = 1 };
 enum isx_blender { ISX_BLEND_ALPHA = 0, ISX_BLEND_GRADIENT = 1 };          /* stitcher.py:153-156 `blender` */
 
 int isx_version(void);
@@ -145,6 +149,12 @@ int isx_bbox_reset(int32_t *bbox_dev, void *stream);
 int isx_warp(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
              const double *M_host, int model, uint8_t *dst_dev, int64_t dpitch, int dx0, int dy0, int dw,
              int dh, int32_t *bbox_out_dev, void *stream);
+/* isx_warp with the arithmetic chosen explicitly (isx_warp = ISX_WARP_LINEAR_F32).  canvas_w/canvas_h =
+ * the dsize of the reference's call (stitcher.py:146, :148: the padded canvas); the classic perspective
+ * path needs it because cv::WarpPerspectiveInvoker evaluates the map per 64-column block of that canvas. */
+int isx_warp_arith(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
+                   const double *M_host, int model, uint8_t *dst_dev, int64_t dpitch, int dx0, int dy0, int dw,
+                   int dh, int arith, int canvas_w, int canvas_h, int32_t *bbox_out_dev, void *stream);
 
 /* Replaces seamless_merge (utils/proc.py:48-82; Stitcher.merge blender=0, stitcher.py:153-154).
  * warped/ref/out are same-size views; out may alias ref. */

@@ -54,6 +54,15 @@ void orc_pad_image(const uint8_t *img, int h, int w, int c, int new_h, int new_w
  * arith 0 ("B", the OpenCV 4.11 linear kernels, modules/imgproc/src/warp_kernels.simd.hpp): the inverse
  * matrix is cast to float32; source coordinates, the two fractional weights and the three lerps are
  * float32 fused multiply-adds; the result is rounded to nearest-even and saturated.
+ *
+ * arith 1 ("A", the classic path of OpenCV <= 4.10, modules/imgproc/src/imgwarp.cpp WarpAffineInvoker /
+ * WarpPerspectiveInvoker + remapBilinear<FixedPtCast<int,uchar,15>>): source coordinates in 1/32 px
+ * fixed point -- affine: X = (cvRound((M1*y + M2)*1024) + 16 + cvRound(M0*x*1024)) >> 5 on the double
+ * inverse; perspective: per pixel in double, W = 32/w, X = cvRound(clamp((X0 + M0*x1)*W)) with X0 taken
+ * at the start of the 64-column block the pixel lies in (bw0/bh0 blocking of the invoker) -- integer part
+ * X>>5 (saturated to short), fraction X&31; bilinear weights from the 32x32 int16 table whose rows sum to
+ * 32768 (entry (0,0) is {32767,0,0,1}: 1.0 saturates to 32767 and the table's sum correction adds the
+ * missing 1 to the last tap); value = (sum(tap*w) + 16384) >> 15; taps outside the image are the border 0.
  */
 static void invert_affine(const double *M, double *iM) {
     double D = M[0] * M[4] - M[1] * M[3];
@@ -85,13 +94,65 @@ static inline float px(const uint8_t *src, int sh, int sw, int c, int x, int y, 
     return (float)src[((long)y * sw + x) * c + ch];
 }
 
+static inline int tap(const uint8_t *src, int sh, int sw, int c, int x, int y, int ch) {
+    if ((unsigned)x >= (unsigned)sw || (unsigned)y >= (unsigned)sh) return 0;
+    return src[((long)y * sw + x) * c + ch];
+}
+
+static inline int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+
+/* cv::saturate_cast<int>(double) = cvRound: round half to even in the default rounding mode */
+static inline int cv_round(double v) { return (int)lrint(v); }
+
+static void warp_classic(const uint8_t *src, int sh, int sw, int c, const double *iM, int perspective,
+                         uint8_t *dst, int dh, int dw) {
+    /* block geometry of WarpPerspectiveInvoker (BLOCK_SZ = 32) */
+    int bh0 = 16 < dh ? 16 : dh;
+    int bw0 = 1024 / bh0 < dw ? 1024 / bh0 : dw;
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            int X, Y;
+            if (!perspective) {
+                const int X0 = cv_round((iM[1] * y + iM[2]) * 1024) + 16;
+                const int Y0 = cv_round((iM[4] * y + iM[5]) * 1024) + 16;
+                X = (X0 + cv_round(iM[0] * x * 1024)) >> 5;
+                Y = (Y0 + cv_round(iM[3] * x * 1024)) >> 5;
+            } else {
+                const int xb = x - x % bw0, x1 = x - xb;
+                const double X0 = iM[0] * xb + iM[1] * y + iM[2];
+                const double Y0 = iM[3] * xb + iM[4] * y + iM[5];
+                const double W0 = iM[6] * xb + iM[7] * y + iM[8];
+                double W = W0 + iM[6] * x1;
+                W = W ? 32. / W : 0;
+                double fX = (X0 + iM[0] * x1) * W, fY = (Y0 + iM[3] * x1) * W;
+                fX = fmax((double)INT32_MIN, fmin((double)INT32_MAX, fX));
+                fY = fmax((double)INT32_MIN, fmin((double)INT32_MAX, fY));
+                X = cv_round(fX);
+                Y = cv_round(fY);
+            }
+            const int ix = sat_short(X >> 5), iy = sat_short(Y >> 5), fx = X & 31, fy = Y & 31;
+            int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+            if (fx == 0 && fy == 0) { w00 = 32767; w11 = 1; }
+            uint8_t *o = dst + ((long)y * dw + x) * c;
+            for (int ch = 0; ch < c; ch++) {
+                const int v = tap(src, sh, sw, c, ix, iy, ch) * w00 + tap(src, sh, sw, c, ix + 1, iy, ch) * w01 +
+                              tap(src, sh, sw, c, ix, iy + 1, ch) * w10 + tap(src, sh, sw, c, ix + 1, iy + 1, ch) * w11;
+                const int r = (v + 16384) >> 15;
+                o[ch] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+            }
+        }
+}
+
 void orc_warp(const uint8_t *src, int sh, int sw, int c, const double *M, int perspective,
               uint8_t *dst, int dh, int dw, int arith) {
     double iMd[9];
     float m[9];
-    (void)arith; /* only "B" is restated so far */
     if (perspective) invert_3x3(M, iMd);
     else { invert_affine(M, iMd); iMd[6] = 0; iMd[7] = 0; iMd[8] = 1; }
+    if (arith == 1) {
+        warp_classic(src, sh, sw, c, iMd, perspective, dst, dh, dw);
+        return;
+    }
     for (int i = 0; i < 9; i++) m[i] = (float)iMd[i];
     for (int y = 0; y < dh; y++)
         for (int x = 0; x < dw; x++) {

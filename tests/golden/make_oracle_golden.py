@@ -78,6 +78,8 @@ def main():
         wa = orc.warp(pimg, M[:2], (Ww, Hh), False)
         wp = orc.warp(pimg, Mp, (Ww, Hh), True)
         out[f"warp{c}_aff"], out[f"warp{c}_hom"] = wa, wp
+        out[f"warp{c}_aff_classic"] = orc.warp(pimg, M[:2], (Ww, Hh), False, arith=1)   # OpenCV <= 4.10 fixed point
+        out[f"warp{c}_hom_classic"] = orc.warp(pimg, Mp, (Ww, Hh), True, arith=1)
         out[f"bbox{c}_aff"] = np.array(orc.bbox_nonzero(wa), np.int32)
         out[f"alpha{c}_02"] = orc.alpha_blend(wa, pref, 0.2)
         out[f"alpha{c}_05"] = orc.alpha_blend(wp, pref, 0.5)

@@ -7,10 +7,11 @@ from oracle import orc
 
 class Cfg:
     def __init__(self, type=0, blender=1, ratio=0.65, min_match_count=5, ref_image_contrib=0.5,
-                 consecutive_range=None):
+                 consecutive_range=None, warp_arith=0):
         self.type, self.blender, self.ratio = type, blender, ratio
         self.min_match_count, self.ref_image_contrib = min_match_count, ref_image_contrib
         self.consecutive_range = consecutive_range
+        self.warp_arith = warp_arith  # 0: OpenCV 4.11 float32 linear kernels, 1: classic fixed point
 
 
 def _kp_xy(kps):
@@ -62,7 +63,7 @@ def oracle_stitch(arg_ref, arg_img, detector, cfg, tf=None, corners=None):
     else:
         M, src_pts, dst_pts = tf
     H, W = reference_image.shape[:2]
-    warped = orc.warp(current_image, M, (W, H), cfg.type == 1)                        # :216
+    warped = orc.warp(current_image, M, (W, H), cfg.type == 1, arith=cfg.warp_arith)  # :216
     if cfg.blender == 0:                                                              # :217
         reference_image = orc.alpha_blend(warped, reference_image, cfg.ref_image_contrib)
     else:

@@ -74,6 +74,9 @@ def test_golden_image_chain(cuda, gold, c):
     wa = ops.warp(dev(img), gold[f"M{c}_aff"], False, (0, 0, W, H), src_xy=(ox, oy), bbox=bb)
     wp = ops.warp(dev(img), gold[f"M{c}_hom"], True, (0, 0, W, H), src_xy=(ox, oy))
     assert np.array_equal(wa.cpu().numpy(), gold[f"warp{c}_aff"]) and np.array_equal(wp.cpu().numpy(), gold[f"warp{c}_hom"])
+    for name, M, persp in (("aff", gold[f"M{c}_aff"], False), ("hom", gold[f"M{c}_hom"], True)):
+        wc = ops.warp(dev(img), M, persp, (0, 0, W, H), src_xy=(ox, oy), arith="classic")
+        assert np.array_equal(wc.cpu().numpy(), gold[f"warp{c}_{name}_classic"])
     corners = ops.bbox_to_corners(bb.cpu().numpy())
     assert np.array_equal(np.array(corners, np.int32), gold[f"bbox{c}_aff"])
     assert np.array_equal(ops.alpha_blend(wa, dev(pref), 0.2).cpu().numpy(), gold[f"alpha{c}_02"])

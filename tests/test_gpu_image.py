@@ -76,6 +76,44 @@ def test_warp_padded_canvas_parity(cuda, orc, c, persp):
         assert np.array_equal(sub, exp[y0:y0 + dh, x0:x0 + dw])
 
 
+@pytest.mark.parametrize("c", [1, 3])
+@pytest.mark.parametrize("persp", [False, True])
+def test_warp_classic_arithmetic_parity(cuda, orc, c, persp):
+    """arith="classic": the fixed-point remap of OpenCV <= 4.10 (oracle arith=1), bit exact, on the full
+    canvas and on a sub-rectangle that does not start on one of the invoker's 64-column blocks."""
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(40 + c + 2 * persp)
+    img = _texture(rng, 96, 128, c)
+    ref = _texture(rng, 150, 210, c)
+    pimg, pref = orc.get_padded_images(img, ref)
+    H, W = pref.shape[:2]
+    ox, oy = (ref.shape[1] + img.shape[1]) // 2, (ref.shape[0] + img.shape[0]) // 2
+    for trial in range(3):
+        th = np.deg2rad(rng.uniform(-8, 8))
+        s = rng.uniform(0.9, 1.1)
+        M = np.array([[s * np.cos(th), -s * np.sin(th), rng.uniform(-60, 60)],
+                      [s * np.sin(th), s * np.cos(th), rng.uniform(-40, 40)], [0, 0, 1]])
+        cx, cy = ox + img.shape[1] / 2, oy + img.shape[0] / 2
+        M[0, 2] += cx - (M[0, 0] * cx + M[0, 1] * cy)
+        M[1, 2] += cy - (M[1, 0] * cx + M[1, 1] * cy)
+        if persp:
+            M[2, :2] = rng.uniform(-1e-4, 1e-4, 2)
+        Mm = M if persp else M[:2]
+        exp = orc.warp(pimg, Mm, (W, H), persp, arith=1)
+        assert (exp != orc.warp(pimg, Mm, (W, H), persp, arith=0)).any()     # the two arithmetics do differ
+        bb = ops.new_bbox(cuda)
+        got = ops.warp(dev(img), Mm, persp, (0, 0, W, H), src_xy=(ox, oy), bbox=bb, arith="classic").cpu().numpy()
+        assert np.array_equal(got, exp), f"{(got != exp).sum()} pixels differ, max {np.abs(got.astype(int) - exp).max()}"
+        assert ops.bbox_to_corners(bb.cpu().numpy()) == orc.bbox_nonzero(exp)
+        x0, y0, dw, dh = 37, 51, 201, 133
+        sub = ops.warp(dev(img), Mm, persp, (x0, y0, dw, dh), src_xy=(ox, oy), arith="classic", canvas=(W, H)).cpu().numpy()
+        assert np.array_equal(sub, exp[y0:y0 + dh, x0:x0 + dw])
+    # exact-copy cases
+    eye = np.eye(3)
+    got = ops.warp(dev(img), eye if persp else eye[:2], persp, (0, 0, img.shape[1], img.shape[0]), arith="classic")
+    assert np.array_equal(got.cpu().numpy(), img)
+
+
 def test_warp_identity_is_copy(cuda):
     from image_stitcher_amd import ops
     rng = np.random.default_rng(5)

@@ -49,6 +49,8 @@ def test_image_chain(orc, gold, c):
     wa = orc.warp(pimg, gold[f"M{c}_aff"], (W, H), False)
     wp = orc.warp(pimg, gold[f"M{c}_hom"], (W, H), True)
     assert np.array_equal(wa, gold[f"warp{c}_aff"]) and np.array_equal(wp, gold[f"warp{c}_hom"])
+    assert np.array_equal(orc.warp(pimg, gold[f"M{c}_aff"], (W, H), False, arith=1), gold[f"warp{c}_aff_classic"])
+    assert np.array_equal(orc.warp(pimg, gold[f"M{c}_hom"], (W, H), True, arith=1), gold[f"warp{c}_hom_classic"])
     assert np.array_equal(np.array(orc.bbox_nonzero(wa), np.int32), gold[f"bbox{c}_aff"])
     assert np.array_equal(orc.alpha_blend(wa, pref, 0.2), gold[f"alpha{c}_02"])
     assert np.array_equal(orc.alpha_blend(wp, pref, 0.5), gold[f"alpha{c}_05"])

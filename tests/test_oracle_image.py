@@ -75,6 +75,62 @@ def test_warp_within_1lsb_of_float64_bilinear(orc, persp):
     assert np.abs(out.astype(np.float64) - np.rint(ref)).mean() < 0.02
 
 
+@pytest.mark.parametrize("c", [1, 3])
+def test_classic_warp_known_answers(orc, c):
+    """arith=1, the fixed-point remap of OpenCV <= 4.10: exact-copy cases, round-half-UP at half pixels
+    (the float32 kernels round half to even), 1/32-px coordinate quantisation."""
+    rng = np.random.default_rng(12)
+    img = rand_img(rng, 31, 45, c)
+    eye = np.eye(3)
+    T = eye.copy()
+    T[0, 2], T[1, 2] = 7, -3
+    exp = np.zeros_like(img)
+    exp[0:28, 7:45] = img[3:31, 0:38]
+    for persp in (False, True):
+        assert np.array_equal(orc.warp(img, eye if persp else eye[:2], (45, 31), persp, arith=1), img)
+        assert np.array_equal(orc.warp(img, T if persp else T[:2], (45, 31), persp, arith=1), exp)
+    # half-pixel shift to the right: out[x] = (img[x-1] + img[x] + 1) >> 1   (weights 16384/16384, +16384 >> 15)
+    H = eye.copy()
+    H[0, 2] = 0.5
+    a = img.astype(np.int32)
+    left = np.zeros_like(a)
+    left[:, 1:] = a[:, :-1]
+    half_up = ((left + a + 1) >> 1).astype(np.uint8)
+    for persp in (False, True):
+        assert np.array_equal(orc.warp(img, H if persp else H[:2], (45, 31), persp, arith=1), half_up)
+    half_even = np.rint((left + a) / 2.0).astype(np.uint8)   # numpy rint = half to even
+    assert np.array_equal(orc.warp(img, H[:2], (45, 31), False, arith=0), half_even)
+    assert (half_up != half_even).any()
+    # coordinates are rounded to the 1/32 grid (the +16 of 1024): a shift of 1/64 px rounds to 0 (a copy),
+    # 3/128 px rounds to 1/32 px = weights (1/32, 31/32) on the pixels (x-1, x)
+    Q = eye.copy()
+    Q[0, 2] = 1.0 / 64
+    assert np.array_equal(orc.warp(img, Q[:2], (45, 31), False, arith=1), img)
+    Q[0, 2] = 3.0 / 128
+    out = orc.warp(img, Q[:2], (45, 31), False, arith=1)
+    w1 = 1024
+    expq = ((left * w1 + a * (32768 - w1) + 16384) >> 15).astype(np.uint8)
+    assert np.array_equal(out, expq)
+
+
+@pytest.mark.parametrize("persp", [False, True])
+def test_classic_warp_within_2lsb_of_float64_bilinear(orc, persp):
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (8, 10, 3)).astype(np.float64)
+    img = np.kron(base, np.ones((8, 8, 1)))
+    img = (0.25 * (img + np.roll(img, 1, 0) + np.roll(img, 1, 1) + np.roll(img, (1, 1), (0, 1)))).astype(np.uint8)
+    th = np.deg2rad(7.0)
+    M = np.array([[np.cos(th), -np.sin(th), 12.3], [np.sin(th), np.cos(th), -4.7], [0, 0, 1]])
+    if persp:
+        M[2, :2] = (1e-4, -2e-4)
+    out = orc.warp(img, M if persp else M[:2], (100, 90), persp, arith=1)
+    ref = np_ref.warp_bilinear_f64(img, np.linalg.inv(M) if persp else np.linalg.inv(M)[:2], (100, 90))
+    # 1/64 px of coordinate quantisation x the steepest gradient of this image, + rounding
+    grad = max(np.abs(np.diff(img.astype(float), axis=0)).max(), np.abs(np.diff(img.astype(float), axis=1)).max())
+    assert np.abs(out.astype(np.float64) - ref).max() <= 1.0 + 2 * grad / 64
+    assert np.abs(out.astype(np.float64) - ref).mean() < 0.5
+
+
 def test_alpha_blend_known_answers(orc):
     # wrap-around outside the overlap: 250 + 8 -> 2 (ref bright, warped dark-but-nonzero, gray <= 10)
     w = np.full((1, 4), 8, np.uint8)
