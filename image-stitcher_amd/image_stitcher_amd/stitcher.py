@@ -297,6 +297,10 @@ class Stitcher:
             img = img._host  # the frame came from the host: no download needed
         x0, y0 = max(0, min(W, p1[0])), max(0, min(H, p1[1]))
         x1, y1 = max(x0, min(W, p2[0])), max(y0, min(H, p2[1]))
+        if x0 >= ox and y0 >= oy and x1 <= ox + img.shape[1] and y1 <= oy + img.shape[0] and x1 > x0 and y1 > y0:
+            # the region lies inside the image (the usual case): a view of the host frame / a download of
+            # just that part of the resident mosaic -- no zero canvas, no second copy
+            return np.asarray(img[y0 - oy:y1 - oy, x0 - ox:x1 - ox])
         c = () if img.ndim == 2 else (img.shape[2],)
         out = np.zeros((y1 - y0, x1 - x0) + c, np.uint8)
         ix0, iy0 = max(x0, ox), max(y0, oy)
