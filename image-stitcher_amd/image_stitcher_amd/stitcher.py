@@ -443,9 +443,9 @@ class ArbitraryStitcher(Stitcher):
             self.images = LazyList(lambda index: load_image(self.filepaths[index], to_resize=self.resize), len(self.filepaths))
         else:
             raise ValueError("No images specified")
-        if with_tqdm is False:
+        if with_tqdm == False:  # noqa: E712  (stitcher.py:250-255 compares with ==: 0 / 1 work too)
             self.tqdm = no_tqdm
-        elif with_tqdm is True:
+        elif with_tqdm == True:  # noqa: E712
             self.tqdm = tqdm
         else:
             self.tqdm = with_tqdm
@@ -603,7 +603,7 @@ class ConsecutiveStitcher(Stitcher):
         self.refs[-1], self.corners, tf = result
         self.image_count += 1
         self.current_image_count += 1
-        if self.backup_interval is not False:
+        if self.backup_interval != False:  # noqa: E712  (the reference's test: 0 and False both mean 'off', stitcher.py:411)
             if self.image_count % self.backup_interval == 0:
                 self.save_last_stitch()
         return tf
