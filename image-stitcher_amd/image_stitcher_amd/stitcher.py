@@ -244,7 +244,7 @@ class Stitcher:
         """Full-canvas warp (API compatibility; `stitch` uses the region path below)."""
         d = DeviceImage.from_any(img, self._dev())
         with torch.cuda.device(self._dev()):
-            out = ops.warp(d.t, M, self.type == 1, (0, 0, ref.shape[1], ref.shape[0]))
+            out = ops.warp(d.t, M, self.type == 1, (0, 0, ref.shape[1], ref.shape[0]), arith=self.warp_arith)
         return DeviceImage(out)
 
     @timer
@@ -326,6 +326,31 @@ class Stitcher:
         y1 = int(np.ceil(xy[:, 1].max())) + 3 + margin
         return max(0, x0), max(0, y0), min(W, x1), min(H, y1)
 
+    def _overridden(self, name):
+        """True when a subclass replaced one of the reference's seam methods (stitcher.py:106-165)."""
+        return getattr(type(self), name) is not getattr(Stitcher, name)
+
+    def _stitch_tail_via_seams(self, img_d, ref_d, M, tf):
+        """stitcher.py:216-229 through the overridable seams, on materialised padded canvases (resident in
+        HBM).  Taken only when a subclass overrides warp_target or merge; the default path below produces
+        the same mosaic from the warped frame's bounding region without building the canvases."""
+        dev = self._dev()
+        current_image, reference_image = get_padded_images(img_d, ref_d, device=dev)
+        warped_image = self.warp_target(current_image, reference_image, M)
+        reference_image = self.merge(warped_image, reference_image)
+        corners = None
+        if self.consecutive_range is not None:
+            corners = get_corners_from_image(warped_image, device=dev)
+            if corners is False:
+                self.logger.warning("Could not get image corners. The merged image has no non-black regions.")
+                corners = None
+        reference_image = crop_image(reference_image, device=dev)
+        if reference_image is False:
+            return None
+        if not self.resident:
+            reference_image = np.ascontiguousarray(np.asarray(reference_image))
+        return reference_image, corners, tf
+
     @timer
     def stitch(self, arg_ref, arg_img, tf=None, corners=None):
         dev = self._dev()
@@ -353,12 +378,18 @@ class Stitcher:
             thisdes = None
             if corners is not None and self.consecutive_range is not None:
                 try:
-                    cur_roi = self._host_region(img_d, ox, oy, H, W, current_corners[0], current_corners[1])
-                    kps, thisdes = self.algorithm_obj.detectAndCompute(cur_roi, None)
-                    thiskp = transform_keypoints_from_roi(kps, current_corners[0])
-                    ref_roi = self._host_region(ref_d, rox, roy, H, W, corners[0], corners[1])
-                    kps, refdes = self.algorithm_obj.detectAndCompute(ref_roi, None)
-                    refkp = transform_keypoints_from_roi(kps, corners[0])
+                    if self._overridden("detectAndComputeFromCorners"):
+                        # a subclass's seam (stitcher.py:159-165): it gets the padded canvases, as in the reference
+                        cur_c, ref_c = get_padded_images(img_d, ref_d, device=dev)
+                        thiskp, thisdes = self.detectAndComputeFromCorners(cur_c, current_corners)
+                        refkp, refdes = self.detectAndComputeFromCorners(ref_c, corners)
+                    else:
+                        cur_roi = self._host_region(img_d, ox, oy, H, W, current_corners[0], current_corners[1])
+                        kps, thisdes = self.algorithm_obj.detectAndCompute(cur_roi, None)
+                        thiskp = transform_keypoints_from_roi(kps, current_corners[0])
+                        ref_roi = self._host_region(ref_d, rox, roy, H, W, corners[0], corners[1])
+                        kps, refdes = self.algorithm_obj.detectAndCompute(ref_roi, None)
+                        refkp = transform_keypoints_from_roi(kps, corners[0])
                 except Exception as e:  # same recovery as stitcher.py:189-191
                     self.logger.warning("Error in detecting keypoints from corners. Computing on whole image. Exception: ", str(e))
                     corners = None
@@ -386,6 +417,8 @@ class Stitcher:
             # the reference passes None to cv2.warp* here, which raises (stitcher.py:208, :216)
             raise RuntimeError("transform estimation failed (cv2 would raise on M=None)")
         M = np.asarray(M, np.float64)
+        if self._overridden("warp_target") or self._overridden("merge"):
+            return self._stitch_tail_via_seams(img_d, ref_d, M, tf)
 
         with torch.cuda.device(dev):
             # warped frame, only where it can be non-zero (+52 px so that the gradient ROI fits)

@@ -331,3 +331,38 @@ def test_stitch_return_contracts(cuda, world, tmp_path):
     assert Counting.calls == before and np.array_equal(np.asarray(res2[0]), np.asarray(mosaic)) and res2[2] is tf
     with pytest.raises(RuntimeError):
         st.stitch(frames[0], frames[1], tf=TransformDetails(None, tf.src_pts, tf.dst_pts))
+
+
+@pytest.mark.parametrize("blender", [0, 1])
+def test_overridden_seams_are_honoured(cuda, world, tmp_path, blender):
+    """A subclass that overrides the reference's seam methods (warp_target / merge /
+    detectAndComputeFromCorners, stitcher.py:143-165) gets them called with padded canvases, as in the
+    reference; with pass-through overrides the mosaic equals the default region path bit for bit."""
+    from image_stitcher_amd import ConsecutiveStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    calls = {"warp": 0, "merge": 0, "detect": 0}
+
+    class Sub(ConsecutiveStitcher):
+        def warp_target(self, img, ref, M):
+            calls["warp"] += 1
+            assert img.shape == ref.shape                     # both are padded canvases
+            return super().warp_target(img, ref, M)
+
+        def merge(self, warped_image, ref):
+            calls["merge"] += 1
+            return super().merge(warped_image, ref)
+
+        def detectAndComputeFromCorners(self, image, corners):
+            calls["detect"] += 1
+            return super().detectAndComputeFromCorners(image, corners)
+    frames = _frames(world, 4)
+    kw = dict(log_level=3, output_dir=str(tmp_path), blender=blender, consecutive_range=1, algorithm=1)
+    a = ConsecutiveStitcher(detector=NumpyOrbLite(nfeatures=600), **kw)
+    b = Sub(detector=NumpyOrbLite(nfeatures=600), **kw)
+    for f in frames:
+        ta, tb = a.stitch_consecutive(f), b.stitch_consecutive(f)
+        assert (ta is None) == (tb is None)
+        if ta is not None:
+            assert np.array_equal(ta.src_pts, tb.src_pts) and np.array_equal(ta.M, tb.M)
+        assert np.array_equal(np.asarray(a.refs[-1]), np.asarray(b.refs[-1])) and a.corners == b.corners
+    assert calls["warp"] == 3 and calls["merge"] == 3 and calls["detect"] == 4   # ROI detection from the 2nd stitch on
