@@ -57,6 +57,11 @@ class IsxError(RuntimeError):
     pass
 
 
+class NormLimitError(IsxError):
+    """2*max||v||^2 reaches ISX_L2_EXACT_LIMIT: squared distances may leave the range where sqrtf is injective,
+    so the integer ranking could differ from cv2's float ranking; the caller falls back to the fp32 matcher."""
+
+
 _lib = None
 
 

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import IsxError, check
+from ._lib import IsxError, NormLimitError, check
 
 
 def _stream():
@@ -99,7 +99,7 @@ def prepare_descriptor_tensor(src, starts, counts, check_range=True):
                                "use the float32 matcher (knn2_f32) instead of the exact integer path")
             max_norm2 = int(s[1])
             if 2 * max_norm2 >= _lib.L2_EXACT_LIMIT:
-                raise IsxError(f"descriptor norms too large for the exact integer path "
+                raise NormLimitError(f"descriptor norms too large for the exact integer path "
                                f"(2*{max_norm2} >= {_lib.L2_EXACT_LIMIT})")
     return PreparedDescriptors(desc, cbase, nrm, cin, starts, counts, d, d_pad, max_norm2)
 

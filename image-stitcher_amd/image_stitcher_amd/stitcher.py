@@ -192,7 +192,13 @@ class Stitcher:
             elif kind == "f32":
                 idx, dist, count = ops.knn2_f32(descriptors_1, descriptors_2, self.lowes_ratio_threshold, self._dev())
             else:
-                idx, dist, count = ops.knn2_l2(descriptors_1, descriptors_2, self.lowes_ratio_threshold)
+                try:
+                    idx, dist, count = ops.knn2_l2(descriptors_1, descriptors_2, self.lowes_ratio_threshold)
+                except ops.NormLimitError:
+                    # dense byte descriptors (e.g. saturated AKAZE/ORB rows): squared distances can exceed the
+                    # range where integer order == cv2's float order; the fp32 matcher computes what cv2 does
+                    f1, f2 = (np.asarray(d, np.float32) for d in (descriptors_1, descriptors_2))
+                    idx, dist, count = ops.knn2_f32(f1, f2, self.lowes_ratio_threshold, self._dev())
         return KnnMatches(idx, dist, count)
 
     def _matcher_kind(self, des):
@@ -518,10 +524,13 @@ class ArbitraryStitcher(Stitcher):
             kinds = {self._matcher_kind(d) for d in self.des if d is not None and len(d)}
             kind = "f32" if "f32" in kinds else (kinds.pop() if kinds else "int")
             if kind == "int":
-                P = ops.prepare_descriptors(self.des, device=dev)
-                items = directed_items(mine, P.starts, P.counts)
-                c = ops.knn2_l2_items(P, items, self.lowes_ratio_threshold).view(-1, 2)
-            else:
+                try:
+                    P = ops.prepare_descriptors(self.des, device=dev)
+                    items = directed_items(mine, P.starts, P.counts)
+                    c = ops.knn2_l2_items(P, items, self.lowes_ratio_threshold).view(-1, 2)
+                except ops.NormLimitError:
+                    kind = "f32"  # see get_matches
+            if kind != "int":
                 des = self.des if kind == "hamming" else [None if d is None else np.asarray(d, np.float32) for d in self.des]
                 c = ops.alt_item_counts(des, lambda st, ct: directed_items(mine, st, ct), kind,
                                         self.lowes_ratio_threshold, dev).view(-1, 2)

@@ -366,3 +366,40 @@ def test_overridden_seams_are_honoured(cuda, world, tmp_path, blender):
             assert np.array_equal(ta.src_pts, tb.src_pts) and np.array_equal(ta.M, tb.M)
         assert np.array_equal(np.asarray(a.refs[-1]), np.asarray(b.refs[-1])) and a.corners == b.corners
     assert calls["warp"] == 3 and calls["merge"] == 3 and calls["detect"] == 4   # ROI detection from the 2nd stitch on
+
+
+def test_saturated_byte_descriptors_fall_back_to_fp32(cuda, orc):
+    """Dense binary descriptors read as bytes (AKAZE/ORB rows full of 0xFF) can push squared L2 distances
+    past 2^22, where sqrtf stops being injective and the integer ranking is no longer provably cv2's float
+    ranking: the int8 path refuses (NormLimitError) and the stitcher routes the pair through the fp32-MFMA
+    matcher, which computes the same float distances as cv2.BFMatcher() does."""
+    from image_stitcher_amd import ArbitraryStitcher, Stitcher, ops
+    rng = np.random.default_rng(61)
+    base = np.where(rng.random((400, 61)) < 0.8, 255, rng.integers(0, 256, (400, 61))).astype(np.uint8)
+    q = base[:300].copy()
+    t = base[100:].copy()
+    flip = rng.random(t.shape) < 0.05
+    t[flip] = rng.integers(0, 256, int(flip.sum()), dtype=np.uint8)
+    with pytest.raises(ops.NormLimitError):
+        ops.knn2_l2(q, t)
+    st = Stitcher(log_level=3)
+    m = st.get_matches(q, t, 2)
+    ridx, rdist = orc.knn2(q, t)
+    assert np.array_equal(m.idx.cpu().numpy(), ridx)
+    assert np.abs(m.dist.cpu().numpy() - rdist).max() <= 1e-4 * rdist.max()
+    good = st.filter_matches(m)
+    gq, gt = orc.ratio_filter(ridx, rdist, 0.65)
+    assert np.array_equal(good.good_q, gq) and np.array_equal(good.good_t, gt)
+
+    class Fixed:                                   # a detector that hands out the prepared descriptors
+        def __init__(self, des):
+            self.des, self.k = des, 0
+
+        def detectAndCompute(self, image, mask=None):
+            d = self.des[self.k]
+            self.k += 1
+            return [None] * len(d), d
+    ar = ArbitraryStitcher(images=[np.zeros((8, 8, 3), np.uint8)] * 2, with_tqdm=False, log_level=3, detector=Fixed([q, t]))
+    ar.get_collections()
+    pairs, counts = ar.good_counts
+    assert counts.tolist() == [[orc.match_count(q, t, 0.65), orc.match_count(t, q, 0.65)]]
