@@ -403,3 +403,23 @@ def test_saturated_byte_descriptors_fall_back_to_fp32(cuda, orc):
     ar.get_collections()
     pairs, counts = ar.good_counts
     assert counts.tolist() == [[orc.match_count(q, t, 0.65), orc.match_count(t, q, 0.65)]]
+
+
+def test_resident_false_returns_ndarrays(cuda, world, tmp_path):
+    """resident=False: refs[-1] and the first element of stitch's result are plain ndarrays (what the reference
+    hands to user code); same pixels as the resident mode; grayscale frames work too (2-D arrays)."""
+    from image_stitcher_amd import ConsecutiveStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    from image_stitcher_amd.device_image import DeviceImage
+    frames = _frames(world, 3)
+    gray = [np.ascontiguousarray(f[..., 1]) for f in frames]
+    for seq in (frames, gray):
+        kw = dict(log_level=3, output_dir=str(tmp_path), consecutive_range=1, algorithm=1)
+        a = ConsecutiveStitcher(detector=NumpyOrbLite(nfeatures=500), **kw)
+        b = ConsecutiveStitcher(detector=NumpyOrbLite(nfeatures=500), resident=False, **kw)
+        for f in seq:
+            a.stitch_consecutive(f)
+            b.stitch_consecutive(f)
+        assert isinstance(a.refs[-1], DeviceImage) and isinstance(b.refs[-1], np.ndarray)
+        assert b.refs[-1].dtype == np.uint8 and b.refs[-1].ndim == seq[0].ndim and b.refs[-1].flags["C_CONTIGUOUS"]
+        assert np.array_equal(np.asarray(a.refs[-1]), b.refs[-1]) and b.refs[-1].shape[1] > seq[0].shape[1]
