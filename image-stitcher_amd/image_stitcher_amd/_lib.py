@@ -20,6 +20,7 @@ SIGNATURES = {
     "isx_version": (c_int, []),
     "isx_last_error": (ctypes.c_char_p, []),
     "isx_device_count": (c_int, []),
+    "isx_union_find": (c_int, [c_int, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "isx_desc_pad": (c_int, [c_int]),
     "isx_desc_prep": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isx_knn2_l2_items": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double,

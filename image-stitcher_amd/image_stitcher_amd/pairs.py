@@ -12,6 +12,7 @@ counts travel back.  Collectives (RCCL when the tensors are on GPU, gloo in the 
 import numpy as np
 import torch
 
+from ._lib import check, lib
 from .utils.structs import DynamicConnectivity
 
 
@@ -40,14 +41,24 @@ def directed_items(pairs, starts, counts):
 
 
 def components_from_counts(n, pairs, counts_ij, counts_ji, min_match_count, n_union_find=None):
-    """Host union-find exactly as stitcher.py:283-300: the reference visits ordered pairs in (i, j)
-    lexicographic order; the component LISTS do not depend on union order (members are listed
-    ascending, components ordered by smallest member, then stable-sorted by length descending).
+    """Host union-find exactly as stitcher.py:283-300.  The reference visits the ORDERED pairs (i, j) in
+    lexicographic order and unions where len(good) >= min_match_count; the same unions are replayed here in
+    the same order (so `connections` ends in the reference's internal state, not only with the same
+    component lists), but only over the pairs that pass -- a few thousand of 261,632 at BASELINE's size.
     n_union_find: the reference sizes the union-find BEFORE dropping empty images (stitcher.py:283)."""
     dc = DynamicConnectivity(n if n_union_find is None else n_union_find)
-    ok = (np.asarray(counts_ij) >= min_match_count) | (np.asarray(counts_ji) >= min_match_count)
-    for (i, j) in pairs[ok]:
-        dc.union(int(i), int(j))
+    pairs = np.asarray(pairs).reshape(-1, 2)
+    e_ij = pairs[np.flatnonzero(np.asarray(counts_ij) >= min_match_count)]
+    e_ji = pairs[np.flatnonzero(np.asarray(counts_ji) >= min_match_count)]
+    first = np.concatenate([e_ij[:, 0], e_ji[:, 1]])
+    second = np.concatenate([e_ij[:, 1], e_ji[:, 0]])
+    order = np.lexsort((second, first))
+    first = np.ascontiguousarray(first[order], np.int32)
+    second = np.ascontiguousarray(second[order], np.int32)
+    parent = np.arange(dc.n, dtype=np.int32)
+    size = np.ones(dc.n, np.int32)
+    check(lib().isx_union_find(dc.n, first.ctypes.data, second.ctypes.data, len(first), parent.ctypes.data, size.ctypes.data))
+    dc.parent, dc.size = parent.tolist(), size.tolist()
     comps = dc.get_connected_components()
     comps = sorted(comps, key=len, reverse=True)
     return comps, dc

@@ -209,6 +209,13 @@ int isx_ransac_refine(int model, double *M_io_dev, const float *src_dev, const f
                       double thr, int refit, int max_iters, uint8_t *mask_out_dev, int32_t *info_out_dev,
                       void *stream);
 
+/* HOST.  Union step of ArbitraryStitcher.get_collections (stitcher.py:283-296): applies union(first[e],
+ * second[e]) for e = 0..m-1 to a DynamicConnectivity state (utils/structs.py:16-42: weighted quick-union,
+ * path halving, ties hang q's root under p's).  parent_io / size_io: n int32 each, initialised by the caller
+ * (parent[i] = i, size[i] = 1) and left in the state the reference's object would have. */
+int isx_union_find(int n, const int32_t *first_host, const int32_t *second_host, int64_t m,
+                   int32_t *parent_io_host, int32_t *size_io_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,3 +50,25 @@ def test_lazy_list():
         pass
     ll.length -= 1
     assert len(ll) == 3
+
+
+def test_components_from_counts_replays_the_reference_loop():
+    """pairs.components_from_counts == the reference's double loop over ordered pairs (stitcher.py:285-300),
+    including the union-find's internal state, on asymmetric random counts."""
+    import numpy as np
+    from image_stitcher_amd import pairs as prs
+    from image_stitcher_amd.utils.structs import DynamicConnectivity
+    rng = np.random.default_rng(0)
+    for n, p_edge, cr in ((40, 0.03, None), (64, 0.01, None), (50, 0.2, 3)):
+        M = (rng.random((n, n)) < p_edge).astype(np.int32) * 9        # M[i, j] = len(good) of the ordered pair i -> j
+        ref = DynamicConnectivity(n + 2)
+        for i in range(n):
+            for j in range(n):
+                if j == i or (cr is not None and abs(i - j) > cr):
+                    continue
+                if M[i, j] >= 5:
+                    ref.union(i, j)
+        exp = sorted(ref.get_connected_components(), key=len, reverse=True)
+        pr = prs.unordered_pairs(n, cr)
+        comps, dc = prs.components_from_counts(n, pr, M[pr[:, 0], pr[:, 1]], M[pr[:, 1], pr[:, 0]], 5, n_union_find=n + 2)
+        assert comps == exp and dc.parent == ref.parent and dc.size == ref.size
