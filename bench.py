@@ -148,6 +148,22 @@ def stitch_workload(dev, n_frames):
         e1.record()
         torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
+    # the same frame through the reference's own sequence on the CPU (stitcher.py:178-179, :216-225: pad both
+    # images into the canvas, corners of the frame, warp the padded frame to canvas size, gradient merge,
+    # corners of the warped image, crop), restated by the oracle -- one frame, it takes seconds
+    from oracle import orc
+    ref_np, img_np = np.asarray(st.refs[-1]), frames[-1]
+    t0 = time.perf_counter()
+    cur, refc = orc.get_padded_images(img_np, ref_np)
+    orc.bbox_nonzero(cur)
+    Hc, Wc = refc.shape[:2]
+    Mc = np.array([[0.9998, -0.0175, 0.15 * 1920], [0.0175, 0.9998, 12.0]])
+    warped = orc.warp(cur, Mc, (Wc, Hc), False)
+    (bx0, by0), (bx1, by1) = orc.bbox_nonzero(warped)
+    gx0, gy0, gx1, gy1 = max(0, bx0 - 50), max(0, by0 - 50), min(Wc, bx1 + 50), min(Hc, by1 + 50)
+    refc[gy0:gy1, gx0:gx1] = orc.gradient_blend(warped[gy0:gy1, gx0:gx1], refc[gy0:gy1, gx0:gx1], 10)
+    orc.bbox_nonzero(refc)
+    cpu_frame_s = time.perf_counter() - t0
     alg_bytes = img.numel() + 2 * roi.numel()
     executed_bytes = img.numel() + 2 * wbuf.numel() + 2 * roi.numel() + roi.numel()  # warp writes, extents+blend read wbuf
     return {
@@ -155,6 +171,9 @@ def stitch_workload(dev, n_frames):
         "frames": k, "stitched": int(ok), "ms_per_frame": wall / k * 1e3,
         "detector": det_name, "detector_ms_per_frame": det.seconds / k * 1e3, "detector_calls": det.calls,
         "hz_excluding_cpu_detection": k / max(wall - det.seconds, 1e-9),
+        "cpu_baseline": {"value": 1.0 / cpu_frame_s, "unit": "frames/s excluding detection", "cores": 1, "kind": "port",
+                         "sample": f"1 frame: pad + warp + gradient merge + 3 bboxes on the {Wc}x{Hc} canvas as the reference "
+                                   f"does them (oracle/orc_image.c), {cpu_frame_s:.2f} s"},
         "config": {"workload": "ConsecutiveStitcher 1920x1080 BGR stream, consecutive_range=2, type=0 (affine partial), "
                                "blender=1 (gradient), binary descriptors matched with L2 as the reference's cv2.BFMatcher() does",
                    "final_mosaic_shape": [int(v) for v in st.refs[-1].shape]},
