@@ -493,6 +493,23 @@ extern "C" int isx_bbox_reset(int32_t *bbox_dev, void *stream) {
 // overlap = gray1>10 & gray2>10; there ref' = (u8)trunc(c*ref), warped' = (u8)trunc((1-c)*warped) in
 // float64; out = warped' + ref' as uint8 (wraps modulo 256).  out may alias ref.
 // ------------------------------------------------------------------------------------------------
+// one pixel of seamless_merge: warped pixel a, reference pixel b (packed B | G<<8 | R<<16 or the gray byte)
+template <int C>
+__device__ __forceinline__ uint32_t alpha_px(uint32_t a, uint32_t b, double contrib, double one_minus) {
+    const bool overlap = gray_px<C>(a) > 10 && gray_px<C>(b) > 10;
+    uint32_t o = 0;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        int va = (a >> (8 * c)) & 255, vb = (b >> (8 * c)) & 255;
+        if (overlap) {
+            vb = (int)(contrib * (double)vb);
+            va = (int)(one_minus * (double)va);
+        }
+        o |= (uint32_t)((va + vb) & 255) << (8 * c);
+    }
+    return o;
+}
+
 template <int C>
 __global__ void __launch_bounds__(256) alpha_blend_kernel(const uint8_t *__restrict__ warped, int64_t wpitch,
                                                           const uint8_t *ref, int64_t rpitch, uint8_t *out,
@@ -515,19 +532,7 @@ __global__ void __launch_bounds__(256) alpha_blend_kernel(const uint8_t *__restr
         if (y >= h) break;
         uint32_t po[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const bool overlap = gray_px<C>(pa[i][k]) > 10 && gray_px<C>(pb[i][k]) > 10;
-            po[k] = 0;
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                int va = (pa[i][k] >> (8 * c)) & 255, vb = (pb[i][k] >> (8 * c)) & 255;
-                if (overlap) {
-                    vb = (int)(contrib * (double)vb);
-                    va = (int)(one_minus * (double)va);
-                }
-                po[k] |= (uint32_t)((va + vb) & 255) << (8 * c);
-            }
-        }
+        for (int k = 0; k < 4; k++) po[k] = alpha_px<C>(pa[i][k], pb[i][k], contrib, one_minus);
         quad_store<C>(out + y * opitch, x, w, po);
     }
 }
@@ -549,6 +554,94 @@ extern "C" int isx_alpha_blend(const uint8_t *warped_dev, int64_t wpitch, const 
     else
         hipLaunchKernelGGL((alpha_blend_kernel<1>), grid, block, 0, st, warped_dev, wpitch, ref_dev, rpitch, out_dev, opitch, h, w, ref_contrib, one_minus);
     return isx_launch_status("alpha_blend_kernel");
+}
+
+// Fused warp + alpha blend (Stitcher.warp_target + Stitcher.merge with blender = 0, stitcher.py:216-217):
+// the warped pixel never goes to memory -- it is produced, its gray != 0 bbox accumulated (stitcher.py:220),
+// blended with the mosaic pixel under it and stored in place.  One pass over the destination rectangle.
+template <int C, bool PERSP, bool CLASSIC>
+__global__ void __launch_bounds__(256) warp_alpha_kernel(const uint8_t *__restrict__ src, const uint8_t *ref,
+                                                         int64_t rpitch, uint8_t *out, int64_t opitch,
+                                                         const WarpParams P, int tiles_x, int n_tiles, int want_bbox,
+                                                         double contrib, double one_minus) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int minx = INT_MAX, miny = INT_MAX, maxx = -1, maxy = -1;
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int lx = (t % tiles_x) * 256 + 4 * lane;
+        const int ly = (t / tiles_x) * 4 + wave;
+        if (ly >= P.dh) continue; // wave-uniform
+        uint32_t pb[4], px[4], po[4];
+        quad_load<C>(ref + (int64_t)ly * rpitch, lx, P.dw, pb);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            px[i] = lx + i >= P.dw ? 0u
+                    : CLASSIC  ? warp_pixel_classic<C, PERSP>(src, P, P.dx0 + lx + i, P.dy0 + ly)
+                               : warp_pixel<C, PERSP>(src, P, P.dx0 + lx + i, P.dy0 + ly);
+#pragma unroll
+        for (int i = 0; i < 4; i++) po[i] = alpha_px<C>(px[i], pb[i], contrib, one_minus);
+        if (lx < P.dw) quad_store<C>(out + (int64_t)ly * opitch, lx, P.dw, po);
+        if (want_bbox) bbox_quad<C>(px, P.dx0 + lx, P.dy0 + ly, minx, miny, maxx, maxy);
+    }
+    if (want_bbox) bbox_block_partial(minx, miny, maxx, maxy);
+}
+
+extern "C" int isx_warp_alpha_blend(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
+                                    const double *M_host, int model, const uint8_t *ref_dev, int64_t rpitch,
+                                    uint8_t *out_dev, int64_t opitch, int dx0, int dy0, int dw, int dh, int arith,
+                                    int canvas_w, int canvas_h, double ref_contrib, int32_t *bbox_out_dev,
+                                    void *stream) {
+    ISX_REQUIRE(c == 1 || c == 3, "channels must be 1 or 3 (got %d)", c);
+    ISX_REQUIRE(model == ISX_MODEL_AFFINE_PARTIAL || model == ISX_MODEL_HOMOGRAPHY, "bad model %d", model);
+    ISX_REQUIRE(arith == ISX_WARP_LINEAR_F32 || arith == ISX_WARP_CLASSIC, "bad warp arithmetic %d", arith);
+    ISX_REQUIRE(M_host, "null M_host");
+    ISX_REQUIRE(sh > 0 && sw > 0 && spitch >= (int64_t)sw * c, "bad source geometry");
+    ISX_REQUIRE(dw >= 0 && dh >= 0 && rpitch >= (int64_t)dw * c && opitch >= (int64_t)dw * c, "bad destination geometry");
+    if (dw == 0 || dh == 0) return ISX_OK;
+    ISX_REQUIRE(src_dev && ref_dev && out_dev, "null device pointer");
+    WarpParams P;
+    double iM[9];
+    if (model == ISX_MODEL_HOMOGRAPHY)
+        invert_3x3_cv(M_host, iM);
+    else
+        invert_affine_cv(M_host, iM);
+    for (int i = 0; i < 9; i++) P.m[i] = (float)iM[i], P.im[i] = iM[i];
+    P.bw0 = 64;
+    if (arith == ISX_WARP_CLASSIC && model == ISX_MODEL_HOMOGRAPHY) {
+        ISX_REQUIRE(canvas_w >= dx0 + dw && canvas_h >= dy0 + dh && dx0 >= 0 && dy0 >= 0,
+                    "classic perspective warp needs the size of the full canvas (got %dx%d)", canvas_w, canvas_h);
+        const int bh0 = canvas_h < 16 ? canvas_h : 16;
+        P.bw0 = 1024 / bh0 < canvas_w ? 1024 / bh0 : canvas_w;
+    }
+    P.src_x = src_x; P.src_y = src_y; P.sh = sh; P.sw = sw;
+    P.dx0 = dx0; P.dy0 = dy0; P.dw = dw; P.dh = dh;
+    P.spitch = spitch; P.dpitch = opitch;
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles_x = (dw + 255) / 256;
+    const int64_t n_tiles64 = (int64_t)tiles_x * ((dh + 3) / 4);
+    ISX_REQUIRE(n_tiles64 < ((int64_t)1 << 31), "destination rectangle too large");
+    const int n_tiles = (int)n_tiles64;
+    const unsigned nblk = (unsigned)(n_tiles < ISX_BBOX_MAX_BLOCKS ? n_tiles : ISX_BBOX_MAX_BLOCKS);
+    dim3 grid(nblk), block(256);
+    const bool persp = model == ISX_MODEL_HOMOGRAPHY, classic = arith == ISX_WARP_CLASSIC;
+    const int wb = bbox_out_dev != nullptr;
+    const double one_minus = 1 - ref_contrib;
+#define ISX_WA_LAUNCH(CC, PP, AA)                                                                                    \
+    hipLaunchKernelGGL((warp_alpha_kernel<CC, PP, AA>), grid, block, 0, st, src_dev, ref_dev, rpitch, out_dev, opitch, P, \
+                       tiles_x, n_tiles, wb, ref_contrib, one_minus)
+    if (c == 3) {
+        if (persp && classic) ISX_WA_LAUNCH(3, true, true);
+        else if (persp) ISX_WA_LAUNCH(3, true, false);
+        else if (classic) ISX_WA_LAUNCH(3, false, true);
+        else ISX_WA_LAUNCH(3, false, false);
+    } else {
+        if (persp && classic) ISX_WA_LAUNCH(1, true, true);
+        else if (persp) ISX_WA_LAUNCH(1, true, false);
+        else if (classic) ISX_WA_LAUNCH(1, false, true);
+        else ISX_WA_LAUNCH(1, false, false);
+    }
+#undef ISX_WA_LAUNCH
+    if (wb) hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(256), 0, st, (int)nblk, bbox_out_dev);
+    return isx_launch_status("warp_alpha_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -39,6 +39,9 @@ SIGNATURES = {
                          c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isx_warp_arith": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "isx_warp_alpha_blend": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64,
+                                     c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double,
+                                     c_void_p, c_void_p]),
     "isx_alpha_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                 c_double, c_void_p]),
     "isx_gradient_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,

@@ -414,6 +414,33 @@ def warp(src, M, perspective, dst_rect, src_xy=(0, 0), out=None, bbox=None, arit
     return out
 
 
+def warp_alpha_blend(src, M, perspective, dst_rect, ref, contrib, src_xy=(0, 0), out=None, bbox=None, arith="f32",
+                     canvas=None):
+    """warp() followed by alpha_blend(warped, ref, contrib) in one pass: `ref` is the view of the mosaic
+    canvas under dst_rect, `out` (default: ref itself, in place) receives the merged pixels; bbox as in warp()."""
+    p, sh, sw, c, spitch = _img_args(src, "src")
+    x0, y0, dw, dh = (int(v) for v in dst_rect)
+    M = np.ascontiguousarray(M, np.float64)
+    if M.shape != ((3, 3) if perspective else (2, 3)):
+        raise IsxError(f"M has shape {M.shape}")
+    if arith not in WARP_ARITH:
+        raise IsxError(f"arith must be one of {sorted(WARP_ARITH)}")
+    pr, rh, rw, rc, rpitch = _img_args(ref, "ref")
+    if out is None:
+        out = ref
+    po, oh, ow, oc, opitch = _img_args(out, "out")
+    if (rh, rw, rc) != (dh, dw, c) or (oh, ow, oc) != (dh, dw, c):
+        raise IsxError("ref / out do not match dst_rect")
+    cw, ch = canvas if canvas is not None else (x0 + dw, y0 + dh)
+    with torch.cuda.device(src.device):
+        check(_lib.lib().isx_warp_alpha_blend(p, sh, sw, c, spitch, int(src_xy[0]), int(src_xy[1]),
+                                              M.ctypes.data_as(ctypes.c_void_p),
+                                              _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL,
+                                              pr, rpitch, po, opitch, x0, y0, dw, dh, WARP_ARITH[arith], int(cw), int(ch),
+                                              float(contrib), _ptr(bbox), _stream()))
+    return out
+
+
 def new_bbox(device):
     with torch.cuda.device(device):
         bb = torch.empty((5,), dtype=torch.int32, device=device)

@@ -431,29 +431,33 @@ class Stitcher:
             qx0, qy0, qx1, qy1 = self._quad_region(M, ox, oy, iw, ih, W, H, 52)
             qw, qh = max(0, qx1 - qx0), max(0, qy1 - qy0)
             shape_c = (C,) if img_d.ndim == 3 else ()
-            wbuf = torch.empty((qh, qw) + shape_c, dtype=torch.uint8, device=dev)
             wbb = ops.new_bbox(dev)
-            ops.warp(img_d.t, M, self.type == 1, (qx0, qy0, qw, qh), src_xy=(ox, oy), out=wbuf, bbox=wbb,
-                     arith=self.warp_arith, canvas=(W, H))
-            wbb_h = wbb.cpu().numpy()
-            wcorners = ops.bbox_to_corners(wbb_h)
-
             # merged canvas restricted to U = bounding rectangle of (ref, warped region)
             ux0, uy0 = min(rox, qx0) if qw and qh else rox, min(roy, qy0) if qw and qh else roy
             ux1, uy1 = max(rox + rw, qx1) if qw and qh else rox + rw, max(roy + rh, qy1) if qw and qh else roy + rh
             U = torch.zeros((uy1 - uy0, ux1 - ux0) + shape_c, dtype=torch.uint8, device=dev)
             ops.copy2d(ref_d.t, U[roy - uy0:roy - uy0 + rh, rox - ux0:rox - ux0 + rw])
-            if qw and qh:
-                if self.blender == 0:
+            if self.blender == 0:
+                # alpha blender: warp + merge fused in one pass over the region, in place on U
+                if qw and qh:
                     uq = U[qy0 - uy0:qy1 - uy0, qx0 - ux0:qx1 - ux0]
-                    ops.alpha_blend(wbuf, uq, self.ref_image_contrib, out=uq)
-                elif wcorners is not False:
+                    ops.warp_alpha_blend(img_d.t, M, self.type == 1, (qx0, qy0, qw, qh), uq, self.ref_image_contrib,
+                                         src_xy=(ox, oy), bbox=wbb, arith=self.warp_arith, canvas=(W, H))
+                wcorners = None  # read back together with the merged bbox below
+            else:
+                wbuf = torch.empty((qh, qw) + shape_c, dtype=torch.uint8, device=dev)
+                ops.warp(img_d.t, M, self.type == 1, (qx0, qy0, qw, qh), src_xy=(ox, oy), out=wbuf, bbox=wbb,
+                         arith=self.warp_arith, canvas=(W, H))
+                wcorners = ops.bbox_to_corners(wbb.cpu().numpy())
+                if qw and qh and wcorners is not False:
                     # seamless_gradient_merge ROI: bbox(warped) +- 50 clipped to the canvas (proc.py:199-205)
                     gx0, gy0 = max(0, wcorners[0][0] - 50), max(0, wcorners[0][1] - 50)
                     gx1, gy1 = min(W, wcorners[1][0] + 50), min(H, wcorners[1][1] + 50)
                     ops.gradient_blend_roi(wbuf[gy0 - qy0:gy1 - qy0, gx0 - qx0:gx1 - qx0],
                                            U[gy0 - uy0:gy1 - uy0, gx0 - ux0:gx1 - ux0])
             mb = ops.bbox_nonzero(U).cpu().numpy()
+            if wcorners is None:
+                wcorners = ops.bbox_to_corners(wbb.cpu().numpy())
 
         if self.consecutive_range is not None:
             corners = wcorners

@@ -161,6 +161,15 @@ int isx_warp_arith(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch
 int isx_alpha_blend(const uint8_t *warped_dev, int64_t wpitch, const uint8_t *ref_dev, int64_t rpitch,
                     uint8_t *out_dev, int64_t opitch, int h, int w, int c, double ref_contrib, void *stream);
 
+/* Stitcher.warp_target followed by Stitcher.merge with blender = 0 (stitcher.py:216-217 -> utils/proc.py:48-82)
+ * in ONE pass over the destination rectangle: the warped pixel is produced as isx_warp_arith produces it,
+ * counted into bbox_out_dev (gray != 0, stitcher.py:220) and alpha-blended with the mosaic pixel under it
+ * (ref_dev; out_dev may alias it).  ref_dev / out_dev point at the rectangle's first pixel. */
+int isx_warp_alpha_blend(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
+                         const double *M_host, int model, const uint8_t *ref_dev, int64_t rpitch,
+                         uint8_t *out_dev, int64_t opitch, int dx0, int dy0, int dw, int dh, int arith,
+                         int canvas_w, int canvas_h, double ref_contrib, int32_t *bbox_out_dev, void *stream);
+
 /* Replaces the ROI body of seamless_gradient_merge (utils/proc.py:207-253; Stitcher.merge blender=1).
  * warped/ref are the two ROI views the reference cuts at proc.py:199-205 (bbox(warped) +- 50 px clipped
  * to the canvas); ref is updated in place.  ext_dev: caller scratch of 2*h + 2*w int32. */

@@ -51,6 +51,17 @@ int main() {
     });
     printf("frame: warp+bbox+gradient blend %7.2f us  algorithmic %6.0f GB/s (frame + 2 x roi = %.1f MB)\n", t,
            (src_b + 2 * roi_b) / t / 1e3, (src_b + 2 * roi_b) / 1e6);
+    t = time_us(200, [&] {
+        IK(isx_bbox_reset(bb, 0));
+        IK(isx_warp(src, sh, sw, C, sw * C, sx, sy, M, 0, wbuf, dw * C, dx0, dy0, dw, dh, bb, 0));
+        IK(isx_alpha_blend(wbuf, dw * C, roi, dw * C, roi, dw * C, dh, dw, C, 0.5, 0));
+    });
+    printf("frame: warp+bbox, alpha blend   %7.2f us  algorithmic %6.0f GB/s\n", t, (src_b + 2 * roi_b) / t / 1e3);
+    t = time_us(200, [&] {
+        IK(isx_bbox_reset(bb, 0));
+        IK(isx_warp_alpha_blend(src, sh, sw, C, sw * C, sx, sy, M, 0, roi, dw * C, roi, dw * C, dx0, dy0, dw, dh, 0, 0, 0, 0.5, bb, 0));
+    });
+    printf("frame: FUSED warp+alpha+bbox    %7.2f us  algorithmic %6.0f GB/s\n", t, (src_b + 2 * roi_b) / t / 1e3);
     t = time_us(200, [&] { CK(hipMemcpyAsync(roi, wbuf, (size_t)dw * dh * C, hipMemcpyDeviceToDevice, 0)); });
     printf("memcpy d2d roi        %7.2f us  %6.0f GB/s (read + write)\n", t, 2 * roi_b / t / 1e3);
     return 0;
