@@ -1,33 +1,23 @@
-"""Thin logging facade with the call shape of the reference's utils/logger.py (positional args joined
-by `sep`)."""
+"""Logging facade with the call shape the stitchers use everywhere: `log.info(a, b, c, sep=" ")` joins its
+positional arguments like print() and forwards one string to a standard `logging.Logger` (the reference's
+utils/logger.py has the same surface).  The six level methods are generated, not written out."""
 import logging
+
+_LEVELS = ("debug", "info", "warning", "error", "critical", "exception")
 
 
 class LogWrapper:
     def __init__(self, logger):
         self.logger = logger
+        for level in _LEVELS:
+            setattr(self, level, self._forwarder(getattr(logger, level)))
 
     @staticmethod
-    def _join(args, sep):
-        return sep.join(str(a) for a in args)
-
-    def debug(self, *args, sep=" "):
-        self.logger.debug(self._join(args, sep))
-
-    def info(self, *args, sep=" "):
-        self.logger.info(self._join(args, sep))
-
-    def warning(self, *args, sep=" "):
-        self.logger.warning(self._join(args, sep))
-
-    def error(self, *args, sep=" "):
-        self.logger.error(self._join(args, sep))
-
-    def critical(self, *args, sep=" "):
-        self.logger.critical(self._join(args, sep))
-
-    def exception(self, *args, sep=" "):
-        self.logger.exception(self._join(args, sep))
+    def _forwarder(emit):
+        def send(*parts, sep=" "):
+            emit(sep.join(map(str, parts)))
+        return send
 
     def off(self):
+        """silence everything below CRITICAL (log_level=0)"""
         self.logger.setLevel(logging.CRITICAL)
