@@ -51,4 +51,4 @@ pr.enable()
 run()
 pr.disable()
 ps = pstats.Stats(pr)
-ps.sort_stats("cumulative").print_stats(45)
+ps.sort_stats("tottime").print_stats(32)
