@@ -22,6 +22,8 @@
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 #define ISX_B2 4194304 /* 1 << 22: count kernel's cin bias, keeps h in [2^20, 2^23) for valid rows; 0 = absent */
 #ifndef ISX_COUNT_WPS
@@ -468,7 +470,13 @@ __device__ __noinline__ void knn2_exact_scan(const int8_t *__restrict__ desc, co
     }
 }
 
-template <int KS>
+// KIND 0: int8 L2 (the text above).  KIND 1: Hamming distance of bit vectors on the matrix pipe -- the rows hold
+// one FP4 (E2M1) nibble per bit, 0.0 or 1.0, and the chain is v_mfma_scale_f32_32x32x64_f8f6f4 (64 nibbles per
+// lane pair and instruction, scales 2^0): popcount(a ^ b) = |a| + |b| - 2 a.b.  The chain starts from
+// C = 512 - |b|/2 (float), so the accumulator is h = 512 + a.b - |b|/2 > 0, exact in float32 (multiples of
+// 1/2 below 1024), and positive floats order like their bit patterns: the same unsigned fold serves both kinds.
+// No parity ambiguity exists here, so KIND 1 has no exact-scan fallback.
+template <int KS, int KIND = 0>
 __global__ void __launch_bounds__(256, ISX_COUNT_WPS)
 knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm,
                   const int32_t *__restrict__ cin, const isx_knn_item *__restrict__ items, int n_items, int nqb, double ratio,
@@ -567,9 +575,22 @@ knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ n
         for (int cb = 0; cb < 2; cb++) {
             v16i ac = {f.cv[0][0], f.cv[0][1], f.cv[0][2], f.cv[0][3], f.cv[1][0], f.cv[1][1], f.cv[1][2], f.cv[1][3],
                        f.cv[2][0], f.cv[2][1], f.cv[2][2], f.cv[2][3], f.cv[3][0], f.cv[3][1], f.cv[3][2], f.cv[3][3]};
+            if constexpr (KIND == 0) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++)
-                ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[ks], qf[2 * p + cb][ks], ac, 0, 0, 0);
+                for (int ks = 0; ks < KS; ks++)
+                    ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.a[ks], qf[2 * p + cb][ks], ac, 0, 0, 0);
+            } else {
+                v16f af = __builtin_bit_cast(v16f, ac);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const v4i &a = f.a[ks], &b = qf[2 * p + cb][ks];
+                    // FP4 operands use the low 128 bits of the 256-bit operand; cbsz = blgp = 4 selects E2M1
+                    af = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0},
+                                                                       v8i{b[0], b[1], b[2], b[3], 0, 0, 0, 0}, af, 4, 4, 0,
+                                                                       0x7f7f7f7f, 0, 0x7f7f7f7f);
+                }
+                ac = __builtin_bit_cast(v16i, af);
+            }
             acc[cb] = ac;
         }
     };
@@ -685,7 +706,16 @@ knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ n
         const bool mine = h == 0 && qi < it.nq;
         bool good = false, amb = false;
         int na = 0;
-        if (mine && H1 != 0u) {
+        if (KIND == 1) {
+            if (mine && H1 != 0u) {
+                good = true; // single-match row: kept unconditionally (stitcher.py:125-126)
+                if (H2 != 0u) {
+                    const float naf = (float)nrm[it.q_start + qi];
+                    const float d0 = naf - 2.f * (__uint_as_float(H1) - 512.f), d1 = naf - 2.f * (__uint_as_float(H2) - 512.f);
+                    good = (double)d0 < ratio * (double)d1; // Hamming distances as float32, ratio in float64
+                }
+            }
+        } else if (mine && H1 != 0u) {
             if (H2 == 0u) {
                 good = true; // single-match row: kept unconditionally (stitcher.py:125-126)
             } else {
@@ -697,8 +727,8 @@ knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ n
                 amb = (g_best != g_worst) || (flags & 1);
             }
         }
-        unsigned long long am = __ballot(amb);
-        while (am) {
+        unsigned long long am = KIND == 0 ? __ballot(amb) : 0ull;
+        while (KIND == 0 && am) {
             const int L = __ffsll((long long)am) - 1;
             am &= am - 1;
             int v1, v2;
@@ -732,6 +762,72 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
     else
         hipLaunchKernelGGL((knn2_count_kernel<1>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
     return isx_launch_status("knn2_count_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hamming on the matrix pipe (opt-in norm="hamming"; binary descriptors of up to 256 bits).
+// isx_hamming_fp4_prep: every bit of a row becomes one FP4 nibble (0x0 = 0.0, 0x2 = 1.0), 128 bytes per row
+// (rows shorter than 32 bytes are zero padded: equal padding on both sides adds nothing to a distance);
+// nrm = popcount, cin = float bits of 512 - popcount/2.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) hamming_fp4_prep_kernel(const uint8_t *__restrict__ src, int64_t rows, int d,
+                                                               uint8_t *__restrict__ desc, int32_t *__restrict__ nrm,
+                                                               int32_t *__restrict__ cin) {
+    // 8 threads per row, 4 source bytes (= 16 output bytes) each
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t row = t >> 3;
+    const int unit = (int)(t & 7);
+    int pc = 0;
+    if (row < rows) {
+        v4i out = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int k = unit * 4 + e;
+            const unsigned byte = k < d ? src[row * d + k] : 0u;
+            pc += __popc(byte);
+            unsigned w = 0; // bit b of the byte -> nibble b of the word
+#pragma unroll
+            for (int b = 0; b < 8; b++) w |= ((byte >> b) & 1u) << (4 * b + 1);
+            out[e] = (int)w;
+        }
+        *(v4i *)(desc + row * 128 + unit * 16) = out;
+    }
+    pc += __shfl_xor(pc, 1);
+    pc += __shfl_xor(pc, 2);
+    pc += __shfl_xor(pc, 4);
+    if (row < rows && unit == 0) {
+        nrm[row] = pc;
+        cin[row] = (int32_t)__float_as_uint(512.f - 0.5f * (float)pc);
+    }
+}
+
+extern "C" int isx_hamming_fp4_prep(const uint8_t *src_dev, int64_t rows, int d, uint8_t *desc_dev, int32_t *nrm_dev,
+                                    int32_t *cin_dev, void *stream) {
+    ISX_REQUIRE(d > 0 && d <= 32, "the FP4 Hamming path takes descriptors of up to 32 bytes (got %d)", d);
+    ISX_REQUIRE(rows >= 0 && rows < ((int64_t)1 << 31) / 8, "rows=%lld out of range", (long long)rows);
+    if (rows == 0) return ISX_OK;
+    ISX_REQUIRE(src_dev && desc_dev && nrm_dev && cin_dev, "null device pointer");
+    ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
+    const unsigned grid = (unsigned)((rows * 8 + 255) / 256);
+    hipLaunchKernelGGL(hamming_fp4_prep_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src_dev, rows, d, desc_dev,
+                       nrm_dev, cin_dev);
+    return isx_launch_status("hamming_fp4_prep_kernel");
+}
+
+extern "C" int isx_knn2_hamming_count_fp4(const uint8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev,
+                                          const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
+                                          int32_t *count_out_dev, void *stream) {
+    ISX_REQUIRE(n_items >= 0 && max_nq >= 0, "negative size");
+    if (n_items == 0 || max_nq == 0) return ISX_OK;
+    ISX_REQUIRE(desc_dev && nrm_dev && cin_dev && items_dev && count_out_dev, "null device pointer");
+    ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
+    const int qpb = 128 * ISX_COUNT_NCB;
+    const int nqb = (max_nq + qpb - 1) / qpb;
+    const int64_t blocks = (int64_t)((n_items + 7) / 8) * 8 * nqb;
+    ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
+    hipLaunchKernelGGL((knn2_count_kernel<4, 1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const int8_t *)desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, 0);
+    return isx_launch_status("knn2_count_kernel<4,1>");
 }
 
 // ------------------------------------------------------------------------------------------------

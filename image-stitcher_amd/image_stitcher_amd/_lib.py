@@ -29,6 +29,8 @@ SIGNATURES = {
                                         c_int, c_void_p]),
     "isx_knn2_hamming_items": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
+    "isx_hamming_fp4_prep": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "isx_knn2_hamming_count_fp4": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
     "isx_f32_norms": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "isx_knn2_f32_items": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),

@@ -282,10 +282,12 @@ def knn2_f32(q, t, ratio=0.65, device=None):
     return idx, dist, cnt[0]
 
 
-def alt_item_counts(des_list, items_of, kind, ratio, device=None):
+def alt_item_counts(des_list, items_of, kind, ratio, device=None, hamming_impl="auto"):
     """Batched good-match counts with the Hamming ("hamming", uint8) or float32 ("f32") matcher.
     des_list: per-image (n_i, d) arrays (None/empty allowed); items_of(starts, counts) -> (m,4) int32 work
-    items in the concatenated row space.  Returns an int32 device tensor of m counts."""
+    items in the concatenated row space.  Returns an int32 device tensor of m counts.
+    hamming_impl: "fp4" = bit vectors through the FP4 matrix pipe (descriptors of up to 32 bytes), "valu" =
+    XOR/popcount kernel, "auto" = fp4 when the width allows it.  Both give the same counts."""
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device())
     dtype = torch.uint8 if kind == "hamming" else torch.float32
@@ -320,7 +322,22 @@ def alt_item_counts(des_list, items_of, kind, ratio, device=None):
         items_dev = torch.from_numpy(items).to(device)
         L = _lib.lib()
         max_nq, max_nt = int(items[:, 1].max()), int(items[:, 3].max())
-        if kind == "hamming":
+        if kind == "hamming" and hamming_impl not in ("auto", "fp4", "valu"):
+            raise IsxError("hamming_impl must be 'auto', 'fp4' or 'valu'")
+        if kind == "hamming" and (hamming_impl == "fp4" or (hamming_impl == "auto" and d <= 32)):
+            if d > 32:
+                raise IsxError("the FP4 Hamming path takes descriptors of up to 32 bytes")
+            rows = allrows.shape[0]
+            fp4 = torch.empty((rows, 128), dtype=torch.uint8, device=device)
+            nrm = torch.empty((rows,), dtype=torch.int32, device=device)
+            cin = torch.empty((rows,), dtype=torch.int32, device=device)
+            check(L.isx_hamming_fp4_prep(_ptr(allrows), rows, d_pad, _ptr(fp4), _ptr(nrm), _ptr(cin), _stream()))
+            run_items, perm, run_dev, inv_dev, _ = plan_items(items, device)  # XCD-aware order, as the L2 path
+            cnt = torch.zeros((len(run_items),), dtype=torch.int32, device=device)
+            check(L.isx_knn2_hamming_count_fp4(_ptr(fp4), _ptr(nrm), _ptr(cin), _ptr(run_dev), len(run_items), max_nq,
+                                               float(ratio), _ptr(cnt), _stream()))
+            out = cnt[inv_dev] if inv_dev is not None else cnt
+        elif kind == "hamming":
             check(L.isx_knn2_hamming_items(_ptr(allrows), d_pad, _ptr(items_dev), m, max_nq, max_nt, float(ratio),
                                            None, None, None, _ptr(out), _stream()))
         else:

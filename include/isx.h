@@ -111,6 +111,18 @@ int isx_knn2_hamming_items(const uint8_t *desc_dev, int d_pad, const isx_knn_ite
                            int max_nq, int max_nt, double ratio, int32_t *idx_out_dev, float *dist_out_dev,
                            const int64_t *out_start_dev, int32_t *count_out_dev, void *stream);
 
+/* Hamming good-match counts on the matrix pipe (opt-in norm = "hamming", binary descriptors of up to 256 bits):
+ * isx_hamming_fp4_prep expands every bit into one FP4 nibble (rows x 128 bytes), nrm = popcount, cin = float
+ * bits of 512 - popcount/2; isx_knn2_hamming_count_fp4 is isx_knn2_l2_count_items on those rows with
+ * v_mfma_scale_f32_32x32x64_f8f6f4: popcount(a ^ b) = |a| + |b| - 2 a.b, exact in float32.  Same counts as
+ * isx_knn2_hamming_items (cv2.BFMatcher(NORM_HAMMING).knnMatch + the ratio loop of stitcher.py:119-127).
+ * No counterpart call in the reference, whose matcher is L2 for every detector (stitcher.py:85). */
+int isx_hamming_fp4_prep(const uint8_t *src_dev, int64_t rows, int d, uint8_t *desc_dev, int32_t *nrm_dev,
+                         int32_t *cin_dev, void *stream);
+int isx_knn2_hamming_count_fp4(const uint8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev,
+                               const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
+                               int32_t *count_out_dev, void *stream);
+
 /* float32 L2 matcher for descriptors that are not integer valued (stitcher.py:106-116 with float
  * descriptors; cv2.SIFT's are integer valued and take the exact path above).  fp32 MFMA, ranking on
  * na + nb - 2ab, winners' distances recomputed directly.  Gate: 1e-4 relative distance.

@@ -80,3 +80,33 @@ def test_f32_integer_valued_matches_exact_path(cuda, orc):
     assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(idx2.cpu().numpy(), ridx)
     assert np.array_equal(dist.cpu().numpy().view(np.int32), rdist.view(np.int32))
     assert int(cnt.item()) == int(cnt2.item())
+
+
+@pytest.mark.parametrize("d", [32, 16, 7])
+def test_hamming_counts_on_the_fp4_matrix_pipe(cuda, orc, d):
+    """Bit vectors as FP4 0/1 nibbles through v_mfma_scale_f32_32x32x64_f8f6f4: the good-match counts equal
+    the XOR/popcount kernel's and the oracle's, on ragged sets with planted neighbours, duplicate rows
+    (ties), a single-row image (single-match rows bypass the ratio test) and all-identical rows."""
+    import torch
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(100 + d)
+    sizes = [1, 2, 33, 257, 700, 129, 64, 500]
+    des = [rng.integers(0, 256, (s, d), dtype=np.uint8) for s in sizes]
+    flips = (rng.random((30, d)) < 0.1) * (1 << rng.integers(0, 8, (30, d)))
+    des[4][10:40] = des[3][5:35] ^ flips.astype(np.uint8)      # planted near neighbours
+    des[4][100] = des[4][101]                                  # duplicate train rows
+    des[5][:] = des[5][0]                                      # every distance ties
+    des[6][:] = 0                                              # zero popcount rows
+    n = len(des)
+    pairs = [(i, j) for i in range(n) for j in range(n) if i != j]
+    items_of = lambda st, ct: np.array([(st[i], ct[i], st[j], ct[j]) for i, j in pairs], np.int32)  # noqa: E731
+    for ratio in (0.65, 0.9):
+        exp = np.array([orc.match_count(des[i], des[j], ratio, norm=orc.NORM_HAMMING) for i, j in pairs], np.int32)
+        got = {impl: ops.alt_item_counts(des, items_of, "hamming", ratio, cuda, hamming_impl=impl).cpu().numpy()
+               for impl in ("valu", "fp4")}
+        assert np.array_equal(got["valu"], exp)
+        assert np.array_equal(got["fp4"], exp), f"fp4 differs on items {np.nonzero(got['fp4'] != exp)[0][:10]}"
+    assert exp.max() > 20
+    with pytest.raises(ops.IsxError):
+        ops.alt_item_counts([rng.integers(0, 256, (8, 61), dtype=np.uint8)] * 2, lambda st, ct: np.array([(0, 8, 8, 8)], np.int32),
+                            "hamming", 0.65, cuda, hamming_impl="fp4")

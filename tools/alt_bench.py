@@ -49,10 +49,14 @@ n_orb, kpo = 512, 500
 rng = np.random.default_rng(5)
 orb = [rng.integers(0, 256, (kpo, 32), dtype=np.uint8) for _ in range(n_orb)]
 items_orb = lambda st, ct: np.array([(st[i], ct[i], st[j], ct[j]) for i in range(n_orb) for j in range(n_orb) if i != j], np.int32)
-dt, c_h = timed(lambda: ops.alt_item_counts(orb, items_orb, "hamming", 0.65, dev), reps=2)
 m = n_orb * (n_orb - 1)
-print(f"hamming {n_orb} img x {kpo} x 32 B: {dt*1e3:8.2f} ms  {dt/(m/2)*1e6:7.3f} us/pair  "
-      f"{m * kpo * kpo * 8 / dt / 1e12:6.2f} T word-ops/s (XOR+popcount per 32-bit word, host item build included)", flush=True)
+res = {}
+for impl in ("valu", "fp4"):
+    dt, c_h = timed(lambda: ops.alt_item_counts(orb, items_orb, "hamming", 0.65, dev, hamming_impl=impl), reps=2)
+    res[impl] = c_h
+    print(f"hamming[{impl:4s}] {n_orb} img x {kpo} x 32 B: {dt*1e3:8.2f} ms  {dt/(m/2)*1e6:7.3f} us/pair "
+          f"(host item build and upload included; kernel times: rocprofv3)", flush=True)
+assert torch.equal(res["valu"], res["fp4"])
 Po = ops.prepare_descriptors(orb, device=dev)
 it_o = items_orb(Po.starts, np.asarray(Po.counts))
 plan_o = ops.plan_items(it_o, dev)
