@@ -215,11 +215,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # ISX_BENCH_BACKEND=gloo is a rehearsal switch: several ranks share the GPUs that exist and exchange through
+    # host memory, so the multi-rank code path can be run on a one-GPU box.  The measured configuration is
+    # one rank per GPU over RCCL ("nccl").
+    backend = os.environ.get("ISX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from image_stitcher_amd import ops, pairs as prs
     from image_stitcher_amd.synthetic import overlapping_crops_descriptors
