@@ -29,6 +29,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef ISX_COUNT_WPS
 #define ISX_COUNT_WPS 3 /* waves per SIMD the count kernel is compiled for */
 #endif
+#ifndef ISX_COUNT_WAVES
+#define ISX_COUNT_WAVES 4 /* waves per workgroup of the count kernel: they share the staged train chunks */
+#endif
 #ifndef ISX_COUNT_NCB
 #define ISX_COUNT_NCB 2 /* 32-query column blocks per wave of the count kernel (2 or 4) */
 #endif
@@ -477,7 +480,7 @@ __device__ __noinline__ void knn2_exact_scan(const int8_t *__restrict__ desc, co
 // 1/2 below 1024), and positive floats order like their bit patterns: the same unsigned fold serves both kinds.
 // No parity ambiguity exists here, so KIND 1 has no exact-scan fallback.
 template <int KS, int KIND = 0>
-__global__ void __launch_bounds__(256, ISX_COUNT_WPS)
+__global__ void __launch_bounds__(64 * ISX_COUNT_WAVES, ISX_COUNT_WPS)
 knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm,
                   const int32_t *__restrict__ cin, const isx_knn_item *__restrict__ items, int n_items, int nqb, double ratio,
                   int32_t *__restrict__ count_out, int flags) {
@@ -496,7 +499,8 @@ knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ n
     if (item_i >= n_items) return;
     const isx_knn_item it = items[item_i];
     constexpr int NCB = ISX_COUNT_NCB, NP = NCB / 2; // column blocks per wave, handled two at a time
-    constexpr int QPW = 32 * NCB, QPB = 4 * QPW;     // queries per wave / per workgroup
+    constexpr int WAVES = ISX_COUNT_WAVES;
+    constexpr int QPW = 32 * NCB, QPB = WAVES * QPW; // queries per wave / per workgroup
     if (qb * QPB >= it.nq) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -534,7 +538,8 @@ knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ n
     const __amdgpu_buffer_rsrc_t rs_cin =
         __builtin_amdgcn_make_buffer_rsrc((void *)(cin + it.t_start), 0, nt * 4, 0x00020000);
     constexpr int ROWS_PP = 1024 / DP;            // rows per 1 KiB piece
-    constexpr int PPW = (CHUNK * DP / 1024) / 4;  // pieces per wave and chunk
+    constexpr int PIECES = CHUNK * DP / 1024;
+    constexpr int PPW = (PIECES + ISX_COUNT_WAVES - 1) / ISX_COUNT_WAVES; // pieces per wave and chunk
     const int r_in = lane / SLOTS;
     const int lane_voff = r_in * DP + (((lane % SLOTS) ^ (((wave * ROWS_PP + r_in) >> SH) & (SLOTS - 1))) << 4);
 #pragma clang diagnostic push
@@ -545,7 +550,8 @@ knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ n
         const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
         for (int k = 0; k < PPW; k++) {
-            const int piece = wv + 4 * k;
+            const int piece = wv + ISX_COUNT_WAVES * k;
+            if (PIECES % ISX_COUNT_WAVES != 0 && piece >= PIECES) break;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_desc, (lds_ptr_t)(smem_lds + bufi * BUF + piece * 1024), 16, lane_voff,
                                                      c * (CHUNK * DP) + piece * 1024, 0, 0);
         }
@@ -749,12 +755,12 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
     if (n_items == 0 || max_nq == 0) return ISX_OK;
     ISX_REQUIRE(desc_dev && nrm_dev && cin_dev && items_dev && count_out_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
-    const int qpb = 128 * ISX_COUNT_NCB; // queries per workgroup
+    const int qpb = 32 * ISX_COUNT_WAVES * ISX_COUNT_NCB; // queries per workgroup
     const int nqb = (max_nq + qpb - 1) / qpb;
     const int64_t blocks = (int64_t)((n_items + 7) / 8) * 8 * nqb;
     ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)blocks), block(256);
+    dim3 grid((unsigned)blocks), block(64 * ISX_COUNT_WAVES);
     if (d_pad == 128)
         hipLaunchKernelGGL((knn2_count_kernel<4>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
     else if (d_pad == 64)
@@ -821,11 +827,11 @@ extern "C" int isx_knn2_hamming_count_fp4(const uint8_t *desc_dev, const int32_t
     if (n_items == 0 || max_nq == 0) return ISX_OK;
     ISX_REQUIRE(desc_dev && nrm_dev && cin_dev && items_dev && count_out_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
-    const int qpb = 128 * ISX_COUNT_NCB;
+    const int qpb = 32 * ISX_COUNT_WAVES * ISX_COUNT_NCB;
     const int nqb = (max_nq + qpb - 1) / qpb;
     const int64_t blocks = (int64_t)((n_items + 7) / 8) * 8 * nqb;
     ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
-    hipLaunchKernelGGL((knn2_count_kernel<4, 1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((knn2_count_kernel<4, 1>), dim3((unsigned)blocks), dim3(64 * ISX_COUNT_WAVES), 0, (hipStream_t)stream,
                        (const int8_t *)desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, 0);
     return isx_launch_status("knn2_count_kernel<4,1>");
 }
