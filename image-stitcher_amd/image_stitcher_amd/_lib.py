@@ -63,6 +63,11 @@ class IsxError(RuntimeError):
     pass
 
 
+class NotIntegerValuedError(IsxError):
+    """float32 descriptors that are not integer valued in [0, 255] (found on the device by isx_desc_prep): the
+    exact int8 path does not apply; the caller uses the fp32 matcher."""
+
+
 class NormLimitError(IsxError):
     """2*max||v||^2 reaches ISX_L2_EXACT_LIMIT: squared distances may leave the range where sqrtf is injective,
     so the integer ranking could differ from cv2's float ranking; the caller falls back to the fp32 matcher."""

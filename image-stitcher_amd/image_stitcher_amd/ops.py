@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import IsxError, NormLimitError, check
+from ._lib import IsxError, NormLimitError, NotIntegerValuedError, check
 
 
 def _stream():
@@ -95,7 +95,7 @@ def prepare_descriptor_tensor(src, starts, counts, check_range=True):
         if check_range:
             s = stats.cpu().numpy()
             if s[0] & 1:
-                raise IsxError("float descriptors are not integer valued in [0,255]: "
+                raise NotIntegerValuedError("float descriptors are not integer valued in [0,255]: "
                                "use the float32 matcher (knn2_f32) instead of the exact integer path")
             max_norm2 = int(s[1])
             if 2 * max_norm2 >= _lib.L2_EXACT_LIMIT:

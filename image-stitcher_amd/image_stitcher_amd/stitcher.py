@@ -186,7 +186,7 @@ class Stitcher:
         if len(descriptors_1) == 0 or len(descriptors_2) == 0:
             return list()  # cv2 knnMatch returns [] for an empty query or train set
         with torch.cuda.device(self._dev()):
-            kind = self._matcher_kind(descriptors_1)
+            kind = self._route(descriptors_1)
             if kind == "hamming":
                 idx, dist, count = ops.knn2_hamming(descriptors_1, descriptors_2, self.lowes_ratio_threshold, self._dev())
             elif kind == "f32":
@@ -194,12 +194,21 @@ class Stitcher:
             else:
                 try:
                     idx, dist, count = ops.knn2_l2(descriptors_1, descriptors_2, self.lowes_ratio_threshold)
-                except ops.NormLimitError:
+                except (ops.NormLimitError, ops.NotIntegerValuedError):
                     # dense byte descriptors (e.g. saturated AKAZE/ORB rows): squared distances can exceed the
-                    # range where integer order == cv2's float order; the fp32 matcher computes what cv2 does
+                    # range where integer order == cv2's float order; float descriptors that are not integer
+                    # valued (found by the device-side check of isx_desc_prep): the fp32 matcher computes what cv2 does
                     f1, f2 = (np.asarray(d, np.float32) for d in (descriptors_1, descriptors_2))
                     idx, dist, count = ops.knn2_f32(f1, f2, self.lowes_ratio_threshold, self._dev())
         return KnnMatches(idx, dist, count)
+
+    def _route(self, des):
+        """_matcher_kind without the host scan of float32 arrays: they are sent to the integer path, whose
+        device-side preparation reports non-integer values (NotIntegerValuedError -> fp32 matcher)."""
+        a = des if isinstance(des, np.ndarray) else np.asarray(des)
+        if a.dtype == np.float32 and self.norm != "hamming":
+            return "int"
+        return self._matcher_kind(a)
 
     def _matcher_kind(self, des):
         """'int' = exact int8-MFMA L2 (uint8, or integer-valued float32 as cv2.SIFT returns), 'f32' = fp32-MFMA
@@ -525,14 +534,14 @@ class ArbitraryStitcher(Stitcher):
         pairs = unordered_pairs(n, self.consecutive_range)
         with torch.cuda.device(dev):
             mine = shard_pairs(pairs, rank, world)
-            kinds = {self._matcher_kind(d) for d in self.des if d is not None and len(d)}
+            kinds = {self._route(d) for d in self.des if d is not None and len(d)}
             kind = "f32" if "f32" in kinds else (kinds.pop() if kinds else "int")
             if kind == "int":
                 try:
                     P = ops.prepare_descriptors(self.des, device=dev)
                     items = directed_items(mine, P.starts, P.counts)
                     c = ops.knn2_l2_items(P, items, self.lowes_ratio_threshold).view(-1, 2)
-                except ops.NormLimitError:
+                except (ops.NormLimitError, ops.NotIntegerValuedError):
                     kind = "f32"  # see get_matches
             if kind != "int":
                 des = self.des if kind == "hamming" else [None if d is None else np.asarray(d, np.float32) for d in self.des]

@@ -423,3 +423,36 @@ def test_resident_false_returns_ndarrays(cuda, world, tmp_path):
         assert isinstance(a.refs[-1], DeviceImage) and isinstance(b.refs[-1], np.ndarray)
         assert b.refs[-1].dtype == np.uint8 and b.refs[-1].ndim == seq[0].ndim and b.refs[-1].flags["C_CONTIGUOUS"]
         assert np.array_equal(np.asarray(a.refs[-1]), b.refs[-1]) and b.refs[-1].shape[1] > seq[0].shape[1]
+
+
+def test_get_collections_float_descriptors(cuda, orc):
+    """cv2.SIFT hands out float32 descriptors with integer values: get_collections takes the exact int8 path
+    for them without scanning the arrays on the host (the device-side preparation checks), and falls back to
+    the fp32 matcher when the values are not integers (RootSIFT-like)."""
+    from image_stitcher_amd import ArbitraryStitcher
+    from image_stitcher_amd.synthetic import overlapping_crops_descriptors
+    des, _ = overlapping_crops_descriptors(seed=31, n_scenes=2, imgs_per_scene=2, kp=600, step=150)
+
+    class Fixed:
+        def __init__(self, arrays):
+            self.arrays, self.k = arrays, 0
+
+        def detectAndCompute(self, image, mask=None):
+            d = self.arrays[self.k]
+            self.k += 1
+            return [None] * len(d), d
+    n = len(des)
+    exp = {(i, j): orc.match_count(des[i], des[j], 0.65) for i in range(n) for j in range(n) if i != j}
+    for arrays, exact in (([d.astype(np.float32) for d in des], True),
+                          ([np.sqrt(d.astype(np.float32)) for d in des], False)):
+        ar = ArbitraryStitcher(images=[np.zeros((8, 8, 3), np.uint8)] * n, with_tqdm=False, log_level=3, detector=Fixed(arrays))
+        cols = ar.get_collections()
+        pairs, counts = ar.good_counts
+        if exact:
+            for (i, j), (cij, cji) in zip(pairs, counts):
+                assert cij == exp[(i, j)] and cji == exp[(j, i)]
+            assert sorted(map(sorted, cols)) == [[0, 1], [2, 3]] or len(cols) == 2
+        else:
+            ref = {(i, j): orc.match_count(arrays[i], arrays[j], 0.65) for i in range(n) for j in range(n) if i != j}
+            for (i, j), (cij, cji) in zip(pairs, counts):
+                assert abs(int(cij) - ref[(i, j)]) <= 2 and abs(int(cji) - ref[(j, i)]) <= 2   # 1e-4 distance tolerance band
