@@ -177,3 +177,29 @@ def test_long_train_and_query_sets(cuda, orc, nq, nt, d):
         q[7] = t[5]
     _check_pair(orc, q, t)
     _count_case(orc, [q, t], 0.8, False)
+
+
+def test_large_ragged_set_sampled_against_the_oracle(cuda, orc):
+    """A realistic get_collections launch: 96 images whose keypoint counts range from 300 to 6000 (SIFT gives
+    what the image gives), all 9,120 ordered pairs in one launch with the XCD-aware item order; 48 items drawn
+    at random -- biased towards the connected ones -- are recounted by the oracle."""
+    import torch
+    from image_stitcher_amd import ops
+    from image_stitcher_amd.synthetic import overlapping_crops_descriptors
+    des, scene_of = overlapping_crops_descriptors(seed=77, n_scenes=3, imgs_per_scene=32, kp=6000, step=700)
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(300, 6001, len(des))
+    lst = [d[:int(s)] for d, s in zip(des, sizes)]
+    P = ops.prepare_descriptors(lst)
+    n = len(lst)
+    pairs = [(i, j) for i in range(n) for j in range(n) if i != j]
+    items = np.array([(P.starts[i], P.counts[i], P.starts[j], P.counts[j]) for i, j in pairs], np.int32)
+    counts = ops.knn2_l2_items(P, items, 0.65)
+    torch.cuda.synchronize()
+    counts = counts.cpu().numpy()
+    strong = np.nonzero(counts >= 5)[0]
+    assert len(strong) > 100 and (counts < 5).sum() > 1000
+    pick = np.concatenate([rng.choice(strong, 24, replace=False), rng.choice(len(pairs), 24, replace=False)])
+    for e in pick:
+        i, j = pairs[e]
+        assert counts[e] == orc.match_count(lst[i], lst[j], 0.65, nthreads=8), (i, j)
