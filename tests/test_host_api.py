@@ -2,6 +2,8 @@
 reference's (stitcher.py:37-50, :233, :378-383), state attributes exist with the reference's initial values,
 error conventions.  No GPU is touched: constructing a stitcher must not need one."""
 import inspect
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -47,3 +49,19 @@ def test_initial_state_and_error_conventions(tmp_path):
     for bad in (dict(norm="l1"), dict(warp_arith="nearest")):
         with pytest.raises(ValueError):
             ConsecutiveStitcher(log_level=3, **bad)
+
+
+def test_image_stitcher_alias_package():
+    """`image-stitcher_amd/compat` makes the reference's import lines resolve to this package's modules."""
+    import subprocess
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "image-stitcher_amd")
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from image_stitcher.stitcher import Stitcher, ArbitraryStitcher, ConsecutiveStitcher, TransformDetails\n"
+            "from image_stitcher.utils.structs import DynamicConnectivity\n"
+            "from image_stitcher.utils import proc, logger, utils\n"
+            "import image_stitcher, image_stitcher_amd.stitcher as s\n"
+            "assert ArbitraryStitcher is s.ArbitraryStitcher and image_stitcher.stitcher is s\n"
+            "assert 'torch.cuda' not in sys.modules or not __import__('torch').cuda.is_initialized()\n"
+            "print('ok')\n") % (root, os.path.join(root, "compat"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
