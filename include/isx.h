@@ -16,8 +16,9 @@
  *   - every function returns 0 on success or a negative isx_status; isx_last_error() returns a
  *     thread-local human readable message for the last failure on the calling thread;
  *   - calls may be issued from any thread and on any stream, with one exception: the entry points that
- *     take a bbox accumulator (`bbox_out_dev`, `bbox_dev`) reduce through one library-owned per-device table, so two such calls
- *     must not be in flight on the same GPU at once (issue them on one stream, or order them by events);
+ *     take a bbox accumulator (`bbox_out_dev`, `bbox_dev`) reduce through one library-owned per-device
+ *     table, so two such calls must not be in flight on the same GPU at once (issue them on one stream,
+ *     or order them by events);
  *   - there is no CPU fallback: without a HIP device the compute entry points fail with ISX_E_HIP.
  */
 #ifndef ISX_H
