@@ -13,7 +13,8 @@ Deliberate differences from the reference:
   * matcher=1 (FLANN, approximate and randomised in cv2) is served by the exact brute-force kernel;
   * mosaics are returned as DeviceImage (array-like; np.asarray() downloads) unless resident=False;
   * keyword-only extensions: detector=, device=, resident=, norm= ('hamming' opts in to the XOR/popcount
-    matcher; the default 'l2' is what the reference's cv2.BFMatcher() computes for every algorithm).
+    matcher; the default 'l2' is what the reference's cv2.BFMatcher() computes for every algorithm),
+    async_save=, warp_arith=, parallel_detect= (see __init__).
 """
 import copy
 import logging
@@ -110,7 +111,8 @@ class Stitcher:
                  blend_processor=lambda x: x,
                  blender=1,
                  ref_image_contrib=0.5,  # Used in alpha blending
-                 *, detector=None, device=None, resident=True, norm="l2", async_save=False, warp_arith="f32"):
+                 *, detector=None, device=None, resident=True, norm="l2", async_save=False, warp_arith="f32",
+                 parallel_detect=False):
         options = {
             "log_level": [logging.DEBUG, logging.INFO, logging.WARNING],
             "algorithm": ["sift", "orb", "akaze"],
@@ -160,6 +162,16 @@ class Stitcher:
         if warp_arith not in ops.WARP_ARITH:
             raise ValueError("warp_arith must be 'f32' or 'classic'")
         self.warp_arith = warp_arith
+        # extension: the two CPU detections of a `stitch` call (frame and reference) run concurrently, the
+        # frame's on a worker thread.  Same results (they are independent); needs either no `detector=`
+        # (two cv2 objects are built), a pair `detector=(a, b)`, or one object that is safe to call from
+        # two threads at once.
+        self.parallel_detect = parallel_detect
+        self._own_detector = False
+        self._detector_b = None
+        if isinstance(detector, (tuple, list)):
+            self._detector, self._detector_b = detector
+        self._pool = None
         self._writer = None
 
     # ---- plumbing -------------------------------------------------------------------------------
@@ -167,7 +179,28 @@ class Stitcher:
     def algorithm_obj(self):
         if self._detector is None:
             self._detector = make_detector(self.algorithm)
+            self._own_detector = True
         return self._detector
+
+    def _detect_two(self, img_a, make_b):
+        """(detectAndCompute(img_a), detectAndCompute(make_b())) -- img_a on a worker thread while this thread
+        fetches and detects the second image when parallel_detect is set, one after the other otherwise."""
+        det = self.algorithm_obj
+        if not self.parallel_detect:
+            ra = det.detectAndCompute(img_a, None)
+            return ra, det.detectAndCompute(make_b(), None)
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(1, thread_name_prefix="isx-detect")
+            if self._detector_b is None:
+                # a caller-supplied single object is used from both threads; our own cv2 objects come in pairs
+                self._detector_b = det if self._own_detector is False else make_detector(self.algorithm)
+        fut = self._pool.submit(self._detector_b.detectAndCompute, img_a, None)
+        try:
+            rb = det.detectAndCompute(make_b(), None)
+        finally:
+            fut.exception()  # never leave the worker running behind an exception of this thread
+        return fut.result(), rb
 
     def _dev(self):
         if self.device is None:
@@ -400,17 +433,16 @@ class Stitcher:
                         refkp, refdes = self.detectAndComputeFromCorners(ref_c, corners)
                     else:
                         cur_roi = self._host_region(img_d, ox, oy, H, W, current_corners[0], current_corners[1])
-                        kps, thisdes = self.algorithm_obj.detectAndCompute(cur_roi, None)
+                        (kps, thisdes), (rkps, refdes) = self._detect_two(
+                            cur_roi, lambda: self._host_region(ref_d, rox, roy, H, W, corners[0], corners[1]))
                         thiskp = transform_keypoints_from_roi(kps, current_corners[0])
-                        ref_roi = self._host_region(ref_d, rox, roy, H, W, corners[0], corners[1])
-                        kps, refdes = self.algorithm_obj.detectAndCompute(ref_roi, None)
-                        refkp = transform_keypoints_from_roi(kps, corners[0])
+                        refkp = transform_keypoints_from_roi(rkps, corners[0])
                 except Exception as e:  # same recovery as stitcher.py:189-191
                     self.logger.warning("Error in detecting keypoints from corners. Computing on whole image. Exception: ", str(e))
                     corners = None
             if corners is None or self.consecutive_range is None or thisdes is None:
-                thiskp, thisdes = self.algorithm_obj.detectAndCompute(self._host_canvas(img_d.numpy(), H, W, ox, oy), None)
-                refkp, refdes = self.algorithm_obj.detectAndCompute(self._host_canvas(ref_d.numpy(), H, W, rox, roy), None)
+                (thiskp, thisdes), (refkp, refdes) = self._detect_two(
+                    self._host_canvas(img_d.numpy(), H, W, ox, oy), lambda: self._host_canvas(ref_d.numpy(), H, W, rox, roy))
 
             if refdes is None:
                 self.logger.warning("Key points not found in ref. Moving to next blend.")

@@ -456,3 +456,51 @@ def test_get_collections_float_descriptors(cuda, orc):
             ref = {(i, j): orc.match_count(arrays[i], arrays[j], 0.65) for i in range(n) for j in range(n) if i != j}
             for (i, j), (cij, cji) in zip(pairs, counts):
                 assert abs(int(cij) - ref[(i, j)]) <= 2 and abs(int(cji) - ref[(j, i)]) <= 2   # 1e-4 distance tolerance band
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("detector_arg", ["single", "pair"])
+def test_parallel_detect_gives_the_same_stream(cuda, world, tmp_path, detector_arg):
+    """parallel_detect=True runs the two CPU detections of a stitch call concurrently (frame on a worker
+    thread): mosaics, corners and transforms are those of the serial stitcher, and a detector that raises on
+    the worker thread is recovered from exactly as on the calling thread (stitcher.py:189-191)."""
+    from image_stitcher_amd import ConsecutiveStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    import threading
+    frames = _frames(world, 6)
+
+    class Recording(NumpyOrbLite):
+        def __init__(self, **kw):
+            super().__init__(**kw)
+            self.threads, self.fail_at, self.calls = set(), None, 0
+
+        def detectAndCompute(self, image, mask=None):
+            self.threads.add(threading.current_thread().name)
+            self.calls += 1
+            if self.calls == self.fail_at:
+                raise RuntimeError("planted detector failure")
+            return super().detectAndCompute(image, mask)
+
+    outs = {}
+    for par in (False, True):
+        a, b = Recording(nfeatures=500), Recording(nfeatures=500)
+        det = a
+        if detector_arg == "pair":
+            # the frame's ROI detection of the second stitch raises: the serial stitcher makes it call 3 of its
+            # one detector (frame, reference, frame, ...), the parallel one call 2 of the worker's detector
+            if par:
+                det, b.fail_at = (a, b), 2
+            else:
+                a.fail_at = 3
+        st = ConsecutiveStitcher(log_level=0, output_dir=str(tmp_path / f"o{par}"), consecutive_range=2, algorithm=1,
+                                 detector=det, parallel_detect=par)
+        rec = []
+        for f in frames:
+            tf = st.stitch_consecutive(f)
+            rec.append((np.array(np.asarray(st.refs[-1])), st.corners, None if tf is None else np.array(tf.M)))
+        outs[par] = rec
+        names = a.threads | b.threads
+        assert any(n.startswith("isx-detect") for n in names) == par
+    for (m0, c0, t0), (m1, c1, t1) in zip(outs[False], outs[True]):
+        assert np.array_equal(m0, m1) and c0 == c1 and (t0 is None) == (t1 is None)
+        assert t0 is None or np.array_equal(t0, t1)
