@@ -83,27 +83,37 @@ def stitch_workload(dev, n_frames):
     from image_stitcher_amd.synthetic import crop_path, procedural_world
     try:
         from image_stitcher_amd.detect import make_detector
-        det, det_name = make_detector(1), "cv2.ORB_create()"
+        new_det = lambda: make_detector(1)
+        det, det_name = new_det(), "cv2.ORB_create()"
     except ImportError:
         from image_stitcher_amd.detect import NumpyOrbLite
-        det, det_name = NumpyOrbLite(nfeatures=1500), "NumpyOrbLite (numpy/scipy stand-in, cv2 absent)"
+        new_det = lambda: NumpyOrbLite(nfeatures=1500)
+        det, det_name = new_det(), "NumpyOrbLite (numpy/scipy stand-in, cv2 absent)"
     det = _TimedDetector(det)
     world = procedural_world(seed=42, h=2160, w=1920 + int(0.15 * 1920 * (n_frames + 4)) + 400)
     frames, _ = crop_path(world, n_frames + 3, (1080, 1920), step_frac=0.15, max_rot_deg=1.0, seed=43)
-    st = ConsecutiveStitcher(log_level=3, output_dir=tempfile.mkdtemp(prefix="isx_bench_"), algorithm=1,
-                             consecutive_range=2, detector=det)
     warm = 3
-    for f in frames[:warm]:
-        st.stitch_consecutive(f)
-    torch.cuda.synchronize()
-    det.seconds, det.calls = 0.0, 0
-    ok = 0
-    t0 = time.perf_counter()
-    for f in frames[warm:]:
-        ok += st.stitch_consecutive(f) is not None
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
     k = len(frames) - warm
+
+    def stream(detector, **kw):
+        st = ConsecutiveStitcher(log_level=3, output_dir=tempfile.mkdtemp(prefix="isx_bench_"), algorithm=1,
+                                 consecutive_range=2, detector=detector, **kw)
+        for f in frames[:warm]:
+            st.stitch_consecutive(f)
+        torch.cuda.synchronize()
+        det.seconds, det.calls = 0.0, 0
+        ok = 0
+        t0 = time.perf_counter()
+        for f in frames[warm:]:
+            ok += st.stitch_consecutive(f) is not None
+        torch.cuda.synchronize()
+        return st, ok, time.perf_counter() - t0
+
+    # the same stream with the frame's and the reference's detections run concurrently (the parallel_detect
+    # extension, two detector objects): same mosaics, reported beside `value`, which is the default configuration
+    st_par, ok_par, wall_par = stream((det.det, new_det()), parallel_detect=True)
+    st, ok, wall = stream(det)
+    same = bool(torch.equal(st.refs[-1].t, st_par.refs[-1].t))
     # kernel-level roofline of warp + feather blend on one representative 1080p frame (HIP events on the
     # launch stream): algorithmic bytes = frame read + mosaic ROI read + write
     img = torch.from_numpy(frames[-1]).to(dev)
@@ -171,6 +181,7 @@ def stitch_workload(dev, n_frames):
         "frames": k, "stitched": int(ok), "ms_per_frame": wall / k * 1e3,
         "detector": det_name, "detector_ms_per_frame": det.seconds / k * 1e3, "detector_calls": det.calls,
         "hz_excluding_cpu_detection": k / max(wall - det.seconds, 1e-9),
+        "parallel_detect": {"value": k / wall_par, "unit": "frames/s", "stitched": int(ok_par), "same_mosaic": same},
         "cpu_baseline": {"value": 1.0 / cpu_frame_s, "unit": "frames/s excluding detection", "cores": 1, "kind": "port",
                          "sample": f"1 frame: pad + warp + gradient merge + 3 bboxes on the {Wc}x{Hc} canvas as the reference "
                                    f"does them (oracle/orc_image.c), {cpu_frame_s:.2f} s"},
