@@ -25,3 +25,12 @@ static inline int isx_launch_status(const char *what) {
     if (e != hipSuccess) return isx_fail(ISX_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
     return ISX_OK;
 }
+
+// HIP forms the global size gridDim.x * blockDim.x in 32 bits: a launch of 2^32 threads or more silently runs
+// a truncated grid.  Launches over an item list are therefore split; this is the number of items per launch
+// (a multiple of 8, which the XCD-aware block -> item maps rely on), 0 if not even 8 items fit.
+static inline int isx_items_per_launch(int blocks_per_item, int threads) {
+    const int64_t max_blocks = ((int64_t)1 << 31) / threads;
+    const int64_t per = (max_blocks / blocks_per_item) & ~(int64_t)7;
+    return (int)(per > (1 << 30) ? (1 << 30) : per);
+}

@@ -395,16 +395,22 @@ extern "C" int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_d
     ISX_REQUIRE(desc_dev && cbase_dev && nrm_dev && items_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
     const int nqb = (max_nq + 255) / 256;
-    const int64_t blocks = (int64_t)((n_items + 7) / 8) * 8 * nqb;
-    ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
+    const int per = isx_items_per_launch(nqb, 256);
+    ISX_REQUIRE(per > 0, "max_nq too large (%d)", max_nq);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)blocks), block(256);
-    if (d_pad == 128)
-        hipLaunchKernelGGL((knn2_l2_kernel<4>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
-    else if (d_pad == 64)
-        hipLaunchKernelGGL((knn2_l2_kernel<2>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
-    else
-        hipLaunchKernelGGL((knn2_l2_kernel<1>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
+    for (int off = 0; off < n_items; off += per) { // one launch unless the list is longer than a grid can be
+        const int n = n_items - off < per ? n_items - off : per;
+        const isx_knn_item *it = items_dev + off;
+        const int64_t *os = out_start_dev ? out_start_dev + off : nullptr;
+        int32_t *co = count_out_dev ? count_out_dev + off : nullptr;
+        dim3 grid((unsigned)((n + 7) / 8 * 8 * nqb)), block(256);
+        if (d_pad == 128)
+            hipLaunchKernelGGL((knn2_l2_kernel<4>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+        else if (d_pad == 64)
+            hipLaunchKernelGGL((knn2_l2_kernel<2>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+        else
+            hipLaunchKernelGGL((knn2_l2_kernel<1>), grid, block, 0, st, desc_dev, cbase_dev, nrm_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+    }
     return isx_launch_status("knn2_l2_kernel");
 }
 
@@ -757,16 +763,21 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
     const int qpb = 32 * ISX_COUNT_WAVES * ISX_COUNT_NCB; // queries per workgroup
     const int nqb = (max_nq + qpb - 1) / qpb;
-    const int64_t blocks = (int64_t)((n_items + 7) / 8) * 8 * nqb;
-    ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
+    const int per = isx_items_per_launch(nqb, 64 * ISX_COUNT_WAVES);
+    ISX_REQUIRE(per > 0, "max_nq too large (%d)", max_nq);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)blocks), block(64 * ISX_COUNT_WAVES);
-    if (d_pad == 128)
-        hipLaunchKernelGGL((knn2_count_kernel<4>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
-    else if (d_pad == 64)
-        hipLaunchKernelGGL((knn2_count_kernel<2>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
-    else
-        hipLaunchKernelGGL((knn2_count_kernel<1>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, flags);
+    for (int off = 0; off < n_items; off += per) { // one launch unless the list is longer than a grid can be
+        const int n = n_items - off < per ? n_items - off : per;
+        const isx_knn_item *it = items_dev + off;
+        int32_t *co = count_out_dev + off;
+        dim3 grid((unsigned)((n + 7) / 8 * 8 * nqb)), block(64 * ISX_COUNT_WAVES);
+        if (d_pad == 128)
+            hipLaunchKernelGGL((knn2_count_kernel<4>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
+        else if (d_pad == 64)
+            hipLaunchKernelGGL((knn2_count_kernel<2>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
+        else
+            hipLaunchKernelGGL((knn2_count_kernel<1>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
+    }
     return isx_launch_status("knn2_count_kernel");
 }
 
@@ -829,10 +840,14 @@ extern "C" int isx_knn2_hamming_count_fp4(const uint8_t *desc_dev, const int32_t
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
     const int qpb = 32 * ISX_COUNT_WAVES * ISX_COUNT_NCB;
     const int nqb = (max_nq + qpb - 1) / qpb;
-    const int64_t blocks = (int64_t)((n_items + 7) / 8) * 8 * nqb;
-    ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
-    hipLaunchKernelGGL((knn2_count_kernel<4, 1>), dim3((unsigned)blocks), dim3(64 * ISX_COUNT_WAVES), 0, (hipStream_t)stream,
-                       (const int8_t *)desc_dev, nrm_dev, cin_dev, items_dev, n_items, nqb, ratio, count_out_dev, 0);
+    const int per = isx_items_per_launch(nqb, 64 * ISX_COUNT_WAVES);
+    ISX_REQUIRE(per > 0, "max_nq too large (%d)", max_nq);
+    for (int off = 0; off < n_items; off += per) {
+        const int n = n_items - off < per ? n_items - off : per;
+        hipLaunchKernelGGL((knn2_count_kernel<4, 1>), dim3((unsigned)((n + 7) / 8 * 8 * nqb)), dim3(64 * ISX_COUNT_WAVES), 0,
+                           (hipStream_t)stream, (const int8_t *)desc_dev, nrm_dev, cin_dev, items_dev + off, n, nqb, ratio,
+                           count_out_dev + off, 0);
+    }
     return isx_launch_status("knn2_count_kernel<4,1>");
 }
 

@@ -96,13 +96,20 @@ extern "C" int isx_knn2_hamming_items(const uint8_t *desc_dev, int d_pad, const 
     ISX_REQUIRE(desc_dev && items_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
     const int nqb = (max_nq + 255) / 256;
-    const int64_t blocks = (int64_t)n_items * nqb;
-    ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
+    const int per = isx_items_per_launch(nqb, 256);
+    ISX_REQUIRE(per > 0, "max_nq too large (%d)", max_nq);
     hipStream_t st = (hipStream_t)stream;
-    if (d_pad == 32)
-        hipLaunchKernelGGL((knn2_hamming_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)desc_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
-    else
-        hipLaunchKernelGGL((knn2_hamming_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t *)desc_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
+    for (int off = 0; off < n_items; off += per) { // one launch unless the list is longer than a grid can be
+        const int n = n_items - off < per ? n_items - off : per;
+        const isx_knn_item *it = items_dev + off;
+        const int64_t *os = out_start_dev ? out_start_dev + off : nullptr;
+        int32_t *co = count_out_dev ? count_out_dev + off : nullptr;
+        dim3 grid((unsigned)((int64_t)n * nqb));
+        if (d_pad == 32)
+            hipLaunchKernelGGL((knn2_hamming_kernel<8>), grid, dim3(256), 0, st, (const uint32_t *)desc_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+        else
+            hipLaunchKernelGGL((knn2_hamming_kernel<16>), grid, dim3(256), 0, st, (const uint32_t *)desc_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+    }
     return isx_launch_status("knn2_hamming_kernel");
 }
 
@@ -273,15 +280,21 @@ extern "C" int isx_knn2_f32_items(const float *desc_dev, const float *nrm_dev, i
     ISX_REQUIRE(desc_dev && nrm_dev && items_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
     const int nqb = (max_nq + 127) / 128;
-    const int64_t blocks = (int64_t)n_items * nqb;
-    ISX_REQUIRE(blocks < ((int64_t)1 << 31), "grid too large (%lld blocks): split the item list", (long long)blocks);
+    const int per = isx_items_per_launch(nqb, 256);
+    ISX_REQUIRE(per > 0, "max_nq too large (%d)", max_nq);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)blocks), block(256);
-    if (d == 128)
-        hipLaunchKernelGGL((knn2_f32_kernel<64>), grid, block, 0, st, desc_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
-    else if (d == 64)
-        hipLaunchKernelGGL((knn2_f32_kernel<32>), grid, block, 0, st, desc_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
-    else
-        hipLaunchKernelGGL((knn2_f32_kernel<16>), grid, block, 0, st, desc_dev, nrm_dev, items_dev, n_items, nqb, ratio, idx_out_dev, dist_out_dev, out_start_dev, count_out_dev);
+    for (int off = 0; off < n_items; off += per) { // one launch unless the list is longer than a grid can be
+        const int n = n_items - off < per ? n_items - off : per;
+        const isx_knn_item *it = items_dev + off;
+        const int64_t *os = out_start_dev ? out_start_dev + off : nullptr;
+        int32_t *co = count_out_dev ? count_out_dev + off : nullptr;
+        dim3 grid((unsigned)((int64_t)n * nqb)), block(256);
+        if (d == 128)
+            hipLaunchKernelGGL((knn2_f32_kernel<64>), grid, block, 0, st, desc_dev, nrm_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+        else if (d == 64)
+            hipLaunchKernelGGL((knn2_f32_kernel<32>), grid, block, 0, st, desc_dev, nrm_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+        else
+            hipLaunchKernelGGL((knn2_f32_kernel<16>), grid, block, 0, st, desc_dev, nrm_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+    }
     return isx_launch_status("knn2_f32_kernel");
 }

@@ -203,3 +203,34 @@ def test_large_ragged_set_sampled_against_the_oracle(cuda, orc):
     for e in pick:
         i, j = pairs[e]
         assert counts[e] == orc.match_count(lst[i], lst[j], 0.65, nthreads=8), (i, j)
+
+
+def test_item_lists_longer_than_one_grid(cuda, orc):
+    """An item list whose grid would pass 2^31 threads (HIP forms gridDim*blockDim in 32 bits and silently
+    truncates: at 2^24 items of one 256-thread workgroup the old single launch ran 5000 of them) is split into
+    launches of at most 2^31 threads inside the entry points: 2^24 + 5000 small items, counts of every item and the
+    indices of items in the first, second and last launch against the oracle."""
+    import torch
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(77)
+    n_img = 24
+    lst = [rng.integers(0, 90, (int(r), 32), dtype=np.uint8) for r in rng.integers(2, 9, n_img)]
+    P = ops.prepare_descriptors(lst)
+    n = (1 << 24) + 5000
+    qi = rng.integers(0, n_img, n)
+    ti = (qi + rng.integers(1, n_img, n)) % n_img
+    st, ct = np.asarray(P.starts), np.asarray(P.counts)
+    items = np.stack([st[qi], ct[qi], st[ti], ct[ti]], axis=1).astype(np.int32)
+    table = np.array([[orc.match_count(lst[i], lst[j], 0.8) if i != j else -1 for j in range(n_img)] for i in range(n_img)])
+    exp = table[qi, ti]
+    for xcd in (False, True):
+        c = ops.knn2_l2_items(P, items, 0.8, xcd_order=xcd).cpu().numpy()
+        assert np.array_equal(c, exp), (xcd, int((c != exp).sum()), int(np.nonzero(c != exp)[0][0]))
+    c2, (idx, dist, starts) = ops.knn2_l2_items(P, items, 0.8, want_matches=True, xcd_order=False)
+    assert np.array_equal(c2.cpu().numpy(), exp)
+    for e in (0, 12345, (1 << 23) - 1, 1 << 23, (1 << 24) - 1, 1 << 24, n - 1):
+        ridx, rdist = orc.knn2(lst[qi[e]], lst[ti[e]])
+        s = int(starts[e])
+        assert np.array_equal(idx[s:s + ct[qi[e]]].cpu().numpy(), ridx)
+        assert np.array_equal(dist[s:s + ct[qi[e]]].cpu().numpy(), rdist)
+    assert exp.min() == 0 and exp.max() >= 3
