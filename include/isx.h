@@ -91,6 +91,8 @@ typedef struct isx_knn_item {
  *   dist_out_dev  : optional float32, same indexing (FLT_MAX where absent)
  *   out_start_dev : int64 per item, first output row of the item (required iff idx/dist given)
  *   count_out_dev : optional int32 per item, MUST be zeroed by the caller; receives len(good_matches)
+ * An item list of any length is accepted: lists whose grid would pass 2^31 threads are run as several
+ * launches on `stream` (true of every *_items entry point below).
  */
 int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_dev, const int32_t *nrm_dev,
                       int d_pad, const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
