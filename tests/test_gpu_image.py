@@ -195,6 +195,38 @@ def test_large_images_exceed_the_capped_grids(cuda, orc):
     assert ops.bbox_to_corners(bb.cpu().numpy()) == orc.bbox_nonzero(exp)
 
 
+def test_mosaic_larger_than_4_gib(cuda, orc):
+    """A resident mosaic of more than 2^32 bytes (large aerial mosaics, BASELINE configs[4]): row offsets inside
+    the kernels are 64-bit.  Known answers: planted pixels for the bounding box, an integer-translation warp
+    (an exact copy in both INTER_LINEAR arithmetics) fused with the alpha blend into the far corner, and a copy."""
+    import torch
+    from image_stitcher_amd import ops
+    H, W = 36100, 40004
+    big = torch.zeros((H, W, 3), dtype=torch.uint8, device=cuda)
+    assert big.numel() > (1 << 32)
+    big[5, 7, 1] = 9
+    big[H - 3, W - 2, 2] = 200
+    assert ops.bbox_to_corners(ops.bbox_nonzero(big).cpu().numpy()) == ((7, 5), (W - 1, H - 2))
+    rng = np.random.default_rng(5)
+    img = rand_img(rng, 301, 403, 3, 12, 256)
+    x0, y0 = W - 500, H - 400                      # canvas position of the frame after the warp
+    M = np.array([[1.0, 0.0, float(x0 - 100)], [0.0, 1.0, float(y0 - 50)]])
+    region = big[y0 - 20:y0 + 330, x0 - 30:x0 + 430]
+    region[:] = 77
+    bb = ops.new_bbox(cuda)
+    ops.warp_alpha_blend(dev(img), M, False, (x0 - 30, y0 - 20, 460, 350), region, 0.25, src_xy=(100, 50), bbox=bb,
+                         canvas=(W, H))
+    exp = np.full((350, 460, 3), 77, np.uint8)
+    exp[20:321, 30:433] = (0.25 * 77) // 1 + np.trunc(0.75 * img.astype(np.float64)).astype(np.uint8)
+    assert np.array_equal(big[y0 - 20:y0 + 330, x0 - 30:x0 + 430].cpu().numpy(), exp)
+    assert ops.bbox_to_corners(bb.cpu().numpy()) == ((x0, y0), (x0 + 403, y0 + 301))
+    out = torch.empty((350, 460, 3), dtype=torch.uint8, device=cuda)
+    ops.copy2d(big[y0 - 20:y0 + 330, x0 - 30:x0 + 430], out)
+    assert np.array_equal(out.cpu().numpy(), exp)
+    mb = ops.bbox_nonzero(big).cpu().numpy()
+    assert ops.bbox_to_corners(mb) == ((7, 5), (W - 1, H - 2))
+
+
 @pytest.mark.parametrize("c", [1, 3])
 @pytest.mark.parametrize("persp,arith", [(False, "f32"), (True, "f32"), (False, "classic"), (True, "classic")])
 def test_fused_warp_alpha_blend(cuda, orc, c, persp, arith):
