@@ -31,7 +31,7 @@ def make_case(n, seed, outlier_frac, persp):
 
 
 @pytest.mark.parametrize("persp", [False, True])
-@pytest.mark.parametrize("n,frac", [(12, 0.0), (150, 0.3), (900, 0.5), (3000, 0.6)])
+@pytest.mark.parametrize("n,frac", [(12, 0.0), (150, 0.3), (900, 0.5), (3000, 0.6), (20000, 0.4)])
 def test_estimate_transform_vs_oracle(cuda, orc, persp, n, frac):
     import torch
     from image_stitcher_amd import ops
