@@ -163,7 +163,7 @@ def test_count_kernel_ratio_boundary_parity_bit(cuda, orc):
     _count_case(orc, [des[0]] + des[22:], 0.5, False)
 
 
-@pytest.mark.parametrize("nq,nt,d", [(96, 70001, 32), (70001, 33, 32), (40, 20000, 128)])
+@pytest.mark.parametrize("nq,nt,d", [(96, 70001, 32), (70001, 33, 32), (40, 20000, 128), (64, 262143, 32)])
 def test_long_train_and_query_sets(cuda, orc, nq, nt, d):
     """Sizes past every internal period: > 2^16 train rows (index packing, 512-row segments, many LDS
     chunks) and > 2^16 queries (grid y / query-block arithmetic), with duplicates planted far apart."""
