@@ -39,8 +39,19 @@ def resize_image(image, to_resize=None):
 
 
 def load_image(filepath, to_resize=None):
-    import cv2
-    return resize_image(cv2.imread(filepath), to_resize)
+    """cv2.imread(filepath) (BGR, 3 channels, alpha dropped; None if unreadable) when cv2 is importable, else the
+    same array through PIL -- the counterpart of async_save.write_image."""
+    try:
+        import cv2
+        image = cv2.imread(filepath)
+    except ImportError:
+        from PIL import Image
+        try:
+            with Image.open(filepath) as im:
+                image = np.ascontiguousarray(np.asarray(im.convert("RGB"))[..., ::-1])
+        except (OSError, ValueError):
+            image = None  # cv2.imread's failure value
+    return resize_image(image, to_resize)
 
 
 def get_corners_from_image(image, device=None):

@@ -504,3 +504,32 @@ def test_parallel_detect_gives_the_same_stream(cuda, world, tmp_path, detector_a
     for (m0, c0, t0), (m1, c1, t1) in zip(outs[False], outs[True]):
         assert np.array_equal(m0, m1) and c0 == c1 and (t0 is None) == (t1 is None)
         assert t0 is None or np.array_equal(t0, t1)
+
+
+@pytest.mark.gpu
+def test_arbitrary_stitcher_from_filepaths(cuda, world, tmp_path):
+    """ArbitraryStitcher(filepaths=...) (stitcher.py:239-246): .png/.jpg paths are kept, others dropped, images
+    are loaded lazily (cv2.imread, or PIL where cv2 is absent) and give the collections of the same arrays
+    passed as images=; an image without descriptors is dropped from filepaths too (stitcher.py:270-275)."""
+    from image_stitcher_amd import ArbitraryStitcher
+    from image_stitcher_amd.async_save import write_image
+    from image_stitcher_amd.detect import NumpyOrbLite
+    frames = _frames(world, 4, seed=3) + [np.zeros((240, 320, 3), np.uint8)]
+    paths = []
+    for k, f in enumerate(frames):
+        paths.append(str(tmp_path / f"f{k}.png"))
+        write_image(paths[-1], f)
+    (tmp_path / "notes.txt").write_text("not an image")
+    kw = dict(with_tqdm=False, log_level=3, algorithm=1, min_match_count=40)
+    a = ArbitraryStitcher(filepaths=paths + [str(tmp_path / "notes.txt")], detector=NumpyOrbLite(nfeatures=500), **kw)
+    b = ArbitraryStitcher(images=list(frames), detector=NumpyOrbLite(nfeatures=500), **kw)
+    assert len(a.filepaths) == 5
+    assert np.array_equal(np.asarray(a.images[2]), frames[2])
+    ca, cb = a.get_collections(), b.get_collections()
+    assert ca == cb and [len(c) for c in ca] == [4, 1]
+    assert a.filepaths == paths[:4] and len(a.images) == 4
+    # the trailing singleton is the reference's phantom (union-find sized before the drop, stitcher.py:283-284):
+    # it indexes past the remaining images in the reference too, so only the real collection is stitched
+    out = a.stitch_collections(ca[:1])
+    ob = b.stitch_collections(cb[:1])
+    assert len(out) == len(ob) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(out, ob))

@@ -65,3 +65,22 @@ def test_image_stitcher_alias_package():
             "print('ok')\n") % (root, os.path.join(root, "compat"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr
+
+
+def test_load_image_round_trip(tmp_path):
+    """load_image(write_image(a)) == a for BGR and gray PNGs (cv2.imread semantics: always 3 channels, BGR;
+    unreadable file -> None), with or without cv2."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "image-stitcher_amd"))
+    from image_stitcher_amd.async_save import write_image
+    from image_stitcher_amd.utils.proc import load_image
+    rng = np.random.default_rng(3)
+    bgr = rng.integers(0, 256, (17, 23, 3), dtype=np.uint8)
+    p = str(tmp_path / "a.png")
+    write_image(p, bgr)
+    assert np.array_equal(load_image(p), bgr)
+    gray = rng.integers(0, 256, (9, 11), dtype=np.uint8)
+    write_image(p, gray)
+    got = load_image(p)
+    assert got.shape == (9, 11, 3) and all(np.array_equal(got[..., k], gray) for k in range(3))
+    (tmp_path / "bad.png").write_bytes(b"not a png")
+    assert load_image(str(tmp_path / "bad.png")) is None
