@@ -533,3 +533,45 @@ def test_arbitrary_stitcher_from_filepaths(cuda, world, tmp_path):
     out = a.stitch_collections(ca[:1])
     ob = b.stitch_collections(cb[:1])
     assert len(out) == len(ob) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(out, ob))
+
+
+@pytest.mark.gpu
+def test_readme_synchronised_flow_through_the_alias_package(cuda, world, tmp_path, monkeypatch):
+    """The reference README's synchronised RGB + depth recipe, written against `image_stitcher.stitcher`
+    (resolved by image-stitcher_amd/compat): the depth stitcher follows the RGB stitcher's transforms and its
+    save_and_reset when a frame cannot be matched, so both end with the same number of mosaics, of the same extent."""
+    import os, sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "image-stitcher_amd")
+    monkeypatch.syspath_prepend(os.path.join(root, "compat"))
+    from image_stitcher.stitcher import ConsecutiveStitcher, TransformDetails
+    from image_stitcher_amd.detect import NumpyOrbLite
+    from image_stitcher_amd.synthetic import procedural_world
+    frames = _frames(world, 5)
+    other = procedural_world(seed=99, h=240, w=320)
+    seq = frames[:3] + [other] + frames[3:]
+    # uint16 depth whose low byte (what the uint8 canvases keep, utils/proc.py:283-291) is never black
+    depth = [(256 * (k + 1) + 20 + (np.arange(f.shape[1])[None, :] + np.arange(f.shape[0])[:, None]) % 200).astype(np.uint16)
+             for k, f in enumerate(seq)]
+    rgb = ConsecutiveStitcher(output_dir=str(tmp_path / "rgb"), matcher=1, algorithm=1, backup_interval=2, consecutive_range=2,
+                              blender=1, log_level=3, min_match_count=40, detector=NumpyOrbLite(nfeatures=500))
+    dep = ConsecutiveStitcher(output_dir=str(tmp_path / "depth"), backup_interval=2, blender=0, ref_image_contrib=0.5,
+                              log_level=3, detector=NumpyOrbLite(nfeatures=500))
+    shapes = []
+    for k, (f, d) in enumerate(zip(seq, depth)):
+        first = rgb.stitch_count == 0
+        tf = rgb.stitch_consecutive(f)
+        if not first and rgb.stitch_count > dep.stitch_count:
+            dep.save_and_reset()
+        tf_d = dep.stitch_consecutive(d, tf)
+        assert tf is None or isinstance(tf, TransformDetails)
+        assert tf_d is tf
+        if rgb.refs[-1] is not None and dep.refs[-1] is not None:
+            shapes.append((rgb.refs[-1].shape[:2], dep.refs[-1].shape[:2]))
+    rgb.save_and_reset()
+    dep.save_and_reset()
+    assert rgb.stitch_count == dep.stitch_count == 2
+    # same mosaics up to the border pixels the feather blender (RGB, blender=1) blends to black and the alpha
+    # blender (depth, blender=0) keeps
+    assert len(shapes) >= 4 and all(abs(a[0] - b[0]) <= 2 and abs(a[1] - b[1]) <= 2 for a, b in shapes)
+    assert max(a[1] for a, _ in shapes) > 400
+    assert sorted(os.listdir(tmp_path / "rgb")) == sorted(os.listdir(tmp_path / "depth"))
