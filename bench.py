@@ -325,7 +325,7 @@ def main():
                        "components_correct": bool(ok)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                          "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic,
-                         "kernel": "knn2_count_kernel<4, 0>", "kernel_ms": k_ms,
+                         "kernel": "knn2_count16_kernel", "kernel_ms": k_ms,
                          "note": "int8 MFMA ops; algorithmic 2*Nq*Nt*D per unordered pair (the kernel executes 2x: one pass per direction)"},
         }
         if world == 1 and not args.no_cpu_baseline:

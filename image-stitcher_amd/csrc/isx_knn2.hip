@@ -753,6 +753,218 @@ knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ n
     if (lane == 0 && good_cnt) atomicAdd(&count_out[item_i], good_cnt);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same count kernel on v_mfma_i32_16x16x64_i8 (128-byte rows, L2 only).  Same staging, same LDS layout,
+// same fold arithmetic and epilogue; what changes is the tile shape: a unit is two 16-row train tiles against
+// the wave's four 16-query column blocks (16 instructions of 16K MACs = the 8 x 32K of the 32x32x32 kernel),
+// a lane owns query (lane & 15) of each column block and sees train rows 4 (lane >> 4) + i of a tile, so the
+// four lanes that share a query merge at the end.  Per MAC the instruction writes half as many accumulator
+// values as 32x32x32; tools/mfma_rate.hip ("shape") measures it 9-11 % faster under the power limit.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64 * ISX_COUNT_WAVES, ISX_COUNT_WPS)
+knn2_count16_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm, const int32_t *__restrict__ cin,
+                    const isx_knn_item *__restrict__ items, int n_items, int nqb, double ratio,
+                    int32_t *__restrict__ count_out, int flags) {
+    constexpr int DP = 128, SLOTS = 8, SH = 1, CHUNK = 128;
+    constexpr int BUF = CHUNK * DP + CHUNK * 4;
+    __shared__ __align__(16) unsigned char smem[3 * BUF];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int k = id >> 3;
+    const int qb = k % nqb;
+    const int item_i = (k / nqb) * 8 + xcd;
+    if (item_i >= n_items) return;
+    const isx_knn_item it = items[item_i];
+    constexpr int NCB = 4, WAVES = ISX_COUNT_WAVES;
+    constexpr int QPW = 16 * NCB, QPB = WAVES * QPW;
+    if (qb * QPB >= it.nq) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, col = lane & 15;
+    const int q0 = qb * QPB + wave * QPW;
+    const int nt = it.nt;
+    const bool wave_live = q0 < it.nq;
+
+    v4i qf[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        const int qi = q0 + cb * 16 + col;
+        const v4i *p = (const v4i *)(desc + (int64_t)(it.q_start + (qi < it.nq ? qi : 0)) * DP);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) qf[cb][ks] = (qi < it.nq) ? p[4 * ks + g] : v4i{0, 0, 0, 0};
+    }
+    unsigned m[NCB][4], G[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        G[cb] = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) m[cb][r] = 0u;
+    }
+    const int n_chunks = (nt + CHUNK - 1) / CHUNK;
+
+    // staging: exactly knn2_count_kernel<4>'s (LDS-DMA, swizzle applied on the global side)
+    const __amdgpu_buffer_rsrc_t rs_desc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(desc + (int64_t)it.t_start * DP), 0, nt * DP, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cin =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(cin + it.t_start), 0, nt * 4, 0x00020000);
+    constexpr int ROWS_PP = 1024 / DP;
+    constexpr int PIECES = CHUNK * DP / 1024;
+    constexpr int PPW = (PIECES + ISX_COUNT_WAVES - 1) / ISX_COUNT_WAVES;
+    const int r_in = lane / SLOTS;
+    const int lane_voff = r_in * DP + (((lane % SLOTS) ^ (((wave * ROWS_PP + r_in) >> SH) & (SLOTS - 1))) << 4);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const unsigned smem_lds = (unsigned)(size_t)smem;
+    auto stage_chunk = [&](int c, int bufi) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int k = 0; k < PPW; k++) {
+            const int piece = wv + ISX_COUNT_WAVES * k;
+            if (PIECES % ISX_COUNT_WAVES != 0 && piece >= PIECES) break;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_desc, (lds_ptr_t)(smem_lds + bufi * BUF + piece * 1024), 16, lane_voff,
+                                                     c * (CHUNK * DP) + piece * 1024, 0, 0);
+        }
+        if (wv < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cin, (lds_ptr_t)(smem_lds + bufi * BUF + CHUNK * DP + wv * 256), 4,
+                                                     lane * 4, c * (CHUNK * 4) + wv * 256, 0, 0);
+    };
+#pragma clang diagnostic pop
+    // LDS fragments of one unit (32 train rows = two 16-row tiles): A operands and the 4 cin values per tile
+    struct Frag {
+        v4i a[2][2];
+        v4i cv[2];
+    };
+    auto read_frag = [&](const unsigned char *base, int u, Frag &f) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int row = u * 32 + t * 16 + col;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const int slot = 4 * ks + g;
+                f.a[t][ks] = *(const v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4));
+            }
+            f.cv[t] = *(const v4i *)(base + CHUNK * DP + (u * 32 + t * 16 + 4 * g) * 4);
+        }
+    };
+    auto mfma_unit = [&](const Frag &f, v4i (&acc)[2][NCB]) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) acc[t][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[t][0], qf[cb][0], f.cv[t], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) acc[t][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[t][1], qf[cb][1], acc[t][cb], 0, 0, 0);
+        }
+    };
+    // fold one unit: per column block 4 streams take (x, y) = the two tiles' values (10 VALU ops per 8 distances)
+    auto fold_unit = [&](const v4i (&acc)[2][NCB]) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                unsigned x0 = (unsigned)acc[0][cb][r], y0 = (unsigned)acc[1][cb][r];
+                unsigned x1 = (unsigned)acc[0][cb][r + 1], y1 = (unsigned)acc[1][cb][r + 1];
+                const unsigned t0 = umed3(m[cb][r], x0, y0);
+                const unsigned t1 = umed3(m[cb][r + 1], x1, y1);
+                asm("" : "+v"(x0));
+                asm("" : "+v"(x1));
+                m[cb][r] = umax3(x0, y0, m[cb][r]);
+                m[cb][r + 1] = umax3(x1, y1, m[cb][r + 1]);
+                G[cb] = umax3(t0, t1, G[cb]);
+            }
+        }
+    };
+
+    if (n_chunks > 0) stage_chunk(0, 0);
+    if (n_chunks > 1) stage_chunk(1, 1);
+    __syncthreads();
+
+    v4i accA[2][NCB], accB[2][NCB];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) accB[t][cb] = v4i{0, 0, 0, 0};
+    Frag f0, f1;
+    if (wave_live) read_frag(smem, 0, f0);
+    int buf = 0;
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
+        if (c + 2 < n_chunks) stage_chunk(c + 2, buf2);
+        const unsigned char *base = smem + buf * BUF;
+        if (wave_live) {
+            read_frag(base, 1, f1);
+            mfma_unit(f0, accA);
+            fold_unit(accB);
+            ISX_STEP_FENCE;
+            read_frag(base, 2, f0);
+            mfma_unit(f1, accB);
+            fold_unit(accA);
+            ISX_STEP_FENCE;
+            read_frag(base, 3, f1);
+            mfma_unit(f0, accA);
+            fold_unit(accB);
+            ISX_STEP_FENCE;
+            read_frag(smem + buf1 * BUF, 0, f0); // published by the previous barrier (unused after the last chunk)
+            mfma_unit(f1, accB);
+            fold_unit(accA);
+            ISX_STEP_FENCE;
+        }
+        __syncthreads();
+        buf = buf1;
+    }
+    if (!wave_live) return;
+    fold_unit(accB);
+
+    int good_cnt = 0;
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        unsigned b1 = 0u, b2 = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const unsigned v = m[cb][r];
+            b2 = umed3(b1, b2, v); // b1 >= b2 throughout
+            b1 = b1 > v ? b1 : v;
+        }
+        b2 = b2 > G[cb] ? b2 : G[cb];
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) { // the four lanes (col, g) of a query
+            const unsigned o1 = __shfl_xor(b1, sh), o2 = __shfl_xor(b2, sh);
+            const unsigned mn = b1 > o1 ? o1 : b1, mx2 = b2 > o2 ? b2 : o2;
+            b1 = b1 > o1 ? b1 : o1;
+            b2 = mn > mx2 ? mn : mx2;
+        }
+        const unsigned H1 = b1, H2 = b2;
+        const int qi = q0 + cb * 16 + col;
+        const bool mine = g == 0 && qi < it.nq;
+        bool good = false, amb = false;
+        int na = 0;
+        if (mine && H1 != 0u) {
+            if (H2 == 0u) {
+                good = true; // single-match row: kept unconditionally (stitcher.py:125-126)
+            } else {
+                na = nrm[it.q_start + qi];
+                const int s0_hi = na - 2 * ((int)H1 - ISX_B2), s1_hi = na - 2 * ((int)H2 - ISX_B2);
+                const int s0_lo = s0_hi > 0 ? s0_hi - 1 : 0, s1_lo = s1_hi > 0 ? s1_hi - 1 : 0;
+                const bool g_best = ratio_good(s0_lo, s1_hi, ratio), g_worst = ratio_good(s0_hi, s1_lo, ratio);
+                good = g_best;
+                amb = (g_best != g_worst) || (flags & 1);
+            }
+        }
+        unsigned long long am = __ballot(amb);
+        while (am) {
+            const int L = __ffsll((long long)am) - 1;
+            am &= am - 1;
+            int v1, v2;
+            knn2_exact_scan<DP>(desc, nrm, it.q_start + __shfl(qi, L), it.t_start, nt, lane, v1, v2);
+            const int nal = __shfl(na, L);
+            if (lane == L) good = ratio_good(nal - v1, nal - v2, ratio);
+        }
+        good_cnt += __popcll(__ballot(good));
+    }
+    if (lane == 0 && good_cnt) atomicAdd(&count_out[item_i], good_cnt);
+}
+
 extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev,
                                        int d_pad, const isx_knn_item *items_dev, int n_items, int max_nq,
                                        double ratio, int32_t *count_out_dev, int flags, void *stream) {
@@ -771,7 +983,9 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
         const isx_knn_item *it = items_dev + off;
         int32_t *co = count_out_dev + off;
         dim3 grid((unsigned)((n + 7) / 8 * 8 * nqb)), block(64 * ISX_COUNT_WAVES);
-        if (d_pad == 128)
+        if (d_pad == 128 && !(flags & 2))
+            hipLaunchKernelGGL(knn2_count16_kernel, grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
+        else if (d_pad == 128)
             hipLaunchKernelGGL((knn2_count_kernel<4>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
         else if (d_pad == 64)
             hipLaunchKernelGGL((knn2_count_kernel<2>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);

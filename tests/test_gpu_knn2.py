@@ -115,15 +115,18 @@ def _count_case(orc, des_list, ratio, verify_all):
                       for i in range(n) for j in range(n) if i != j and P.counts[i] and P.counts[j]], np.int32)
     pairs = [(i, j) for i in range(n) for j in range(n) if i != j and P.counts[i] and P.counts[j]]
     c = ops.knn2_l2_items(P, items, ratio, verify_all=verify_all)
+    # flags bit 1: 128-byte rows on the 32x32x32 MFMA kernel instead of the default 16x16x64 one
+    c_alt = ops.knn2_l2_items(P, items, ratio, verify_all=int(verify_all) ^ 2)
     c_idx, _ = ops.knn2_l2_items(P, items, ratio, want_matches=True)
     torch.cuda.synchronize()
-    c, c_idx = c.cpu().numpy(), c_idx.cpu().numpy()
+    c, c_alt, c_idx = c.cpu().numpy(), c_alt.cpu().numpy(), c_idx.cpu().numpy()
     exp = np.array([orc.match_count(des_list[i], des_list[j], ratio) for i, j in pairs], np.int32)
     assert np.array_equal(c_idx, exp)
     assert np.array_equal(c, exp), f"count kernel differs on {np.nonzero(c != exp)[0][:10]}"
+    assert np.array_equal(c_alt, exp), f"count kernel (other MFMA shape) differs on {np.nonzero(c_alt != exp)[0][:10]}"
 
 
-@pytest.mark.parametrize("verify_all", [False, 1, 3])
+@pytest.mark.parametrize("verify_all", [False, 1])
 def test_count_kernel_matches_oracle_sift_like(cuda, orc, verify_all):
     from image_stitcher_amd.synthetic import overlapping_crops_descriptors
     des, _ = overlapping_crops_descriptors(seed=11, n_scenes=2, imgs_per_scene=3, kp=700, step=100)

@@ -165,6 +165,54 @@ __global__ void __launch_bounds__(256, 2) mfma_lds_kernel(unsigned *out, int ite
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// The same MACs per iteration through v_mfma_i32_16x16x64_i8 (32 instructions of 16K MACs instead of 16 of 32K):
+// is the energy per MAC -- and with it the clock -- different for the other int8 shape?  4 column blocks of 16
+// queries, 2 k-steps of 64, NV max3 per 8 instructions-equivalents as above.
+template <int NV>
+__global__ void __launch_bounds__(256, 2) mfma16_kernel(unsigned *out, int iters, int seed) {
+    extern __shared__ char dyn_c[];
+    const char *dyn = dyn_c;
+    const int lane = threadIdx.x;
+    v4i a[2], b[4][2];
+    for (int i = 0; i < 2; i++) {
+        a[i] = v4i{rnd(seed, lane * 64 + i), rnd(seed, lane * 64 + i + 4), rnd(seed, lane * 64 + i + 8), rnd(seed, lane * 64 + i + 12)};
+        for (int cb = 0; cb < 4; cb++)
+            b[cb][i] = v4i{rnd(seed, lane * 64 + i + 16 + 7 * cb), rnd(seed, lane * 64 + i + 20 + 7 * cb), rnd(seed, lane * 64 + i + 24 + 7 * cb),
+                           rnd(seed, lane * 64 + i + 28 + 7 * cb)};
+    }
+    v4i cin{seed, seed + 1, seed + 2, seed + 3};
+    v4i X[2][4];
+    for (int t = 0; t < 2; t++)
+        for (int cb = 0; cb < 4; cb++) X[t][cb] = cin;
+    unsigned m[2][8];
+    for (int i = 0; i < 8; i++) m[0][i] = m[1][i] = 0u;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) { // 4 train tiles of 16 rows x 4 column blocks x 2 k-steps = 32 instructions
+            for (int i = 0; i < 2; i++) asm volatile("" : "+v"(a[i]));
+            const v4i(&Y)[4] = X[(t + 1) & 1];
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++) {
+                v4i ac = cin;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) ac = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks], b[cb][ks], ac, 0, 0, 0);
+                X[t & 1][cb] = ac;
+#pragma unroll
+                for (int u = 0; u < NV / 8; u++) // NV per 8 x 32K MACs = NV/8 per 2 of these instructions
+                    asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(m[cb & 1][u & 7]) : "v"(Y[cb][u & 3]), "v"(Y[(cb + 1) & 3][(u + 1) & 3]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    unsigned s = 0;
+    for (int i = 0; i < 8; i++) s += m[0][i] + m[1][i];
+    for (int t = 0; t < 2; t++)
+        for (int cb = 0; cb < 4; cb++)
+            for (int i = 0; i < 4; i++) s += X[t][cb][i];
+    if (dyn[0] == 77) s++;
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 typedef void (*kern_t)(unsigned *, int, int);
 
 static void run(const char *name, kern_t k, unsigned *out, int wps, int seed) {
@@ -193,9 +241,20 @@ static void run(const char *name, kern_t k, unsigned *out, int wps, int seed) {
            best, ns, 32.0 / ns, 65536.0 / ns * 1024 / 1e3);
 }
 
-int main() {
+int main(int argc, char **argv) {
     unsigned *out;
     CK(hipMalloc(&out, 256 * 4 * 256 * sizeof(unsigned)));
+    if (argc > 1 && argv[1][0] == 's') { // "shape": 32x32x32 against 16x16x64, same MACs ("MFMA" = 32K MACs in both)
+        for (int seed = 2; seed <= 4; seed++)
+            for (int wps = 2; wps <= 3; wps++) {
+                run("32x32x32 nv0", mfma_kernel<0, 0>, out, wps, seed);
+                run("16x16x64 nv0", mfma16_kernel<0>, out, wps, seed);
+                run("32x32x32 nv40", mfma_kernel<40, 1>, out, wps, seed);
+                run("16x16x64 nv40", mfma16_kernel<40>, out, wps, seed);
+            }
+        CK(hipFree(out));
+        return 0;
+    }
     for (int seed = 2; seed <= 4; seed++)
         for (int wps = 1; wps <= 3; wps++) {
             run("nv0", mfma_kernel<0, 0>, out, wps, seed);
