@@ -32,11 +32,41 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _stale(obj, src, force):
+    if force or not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [src, os.path.abspath(__file__), os.path.join(HERE, "..", "include", "isx.h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
 def build(force=False, verbose=True):
+    """One object per source (compiled in parallel, only when stale), then one link."""
     if not force and not needs_build():
         return OUT
+    from concurrent.futures import ThreadPoolExecutor
+    obj_dir = os.path.join(HERE, "build", "obj")
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-x", "hip"] + sources() + ["-o", OUT]
+    os.makedirs(obj_dir, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"]
+    jobs = []
+    for src in sources():
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
+        jobs.append((src, obj, _stale(obj, src, force)))
+
+    def compile_one(job):
+        src, obj, stale = job
+        if stale:
+            cmd = [HIPCC] + compile_flags + ["-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as pool:
+        objs = list(pool.map(compile_one, jobs))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

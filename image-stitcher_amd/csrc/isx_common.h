@@ -34,3 +34,8 @@ static inline int isx_items_per_launch(int blocks_per_item, int threads) {
     const int64_t per = (max_blocks / blocks_per_item) & ~(int64_t)7;
     return (int)(per > (1 << 30) ? (1 << 30) : per);
 }
+
+// bbox of gray != 0 pixels: init + per-block partials into partial_dev (ISX_BBOX_PARTIAL_BLOCKS*4 int32 of device
+// scratch) + finish into result_dev (5 int32).  Shared by isx_bbox_nonzero and its static-scratch variant.
+int isx_bbox_nonzero_launch(const uint8_t *img_dev, int h, int w, int c, int64_t pitch, int32_t *result_dev,
+                            int32_t *partial_dev, hipStream_t st);

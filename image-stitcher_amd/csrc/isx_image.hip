@@ -102,16 +102,17 @@ __global__ void bbox_init_kernel(int32_t *bb) {
 }
 
 // Bounding boxes are reduced in two kernels: every workgroup stores its partial box with plain stores
-// into a library-owned table, and a one-workgroup kernel on the same stream folds the table into the
-// caller's 5-int accumulator.  (Atomics on the accumulator itself serialise: all workgroups finish
-// together, read the same untouched bounds and then queue ~10^4 atomics on one cache line -- measured
-// +50 us on a 13 us warp.)  The table is per device and shared by every call: bbox-producing calls must
-// not overlap on one GPU (the host layer issues them on one stream).
-#define ISX_BBOX_MAX_BLOCKS 2048
-static __device__ int32_t g_bbox_partial[ISX_BBOX_MAX_BLOCKS * 4];
+// into a table, and a one-workgroup kernel on the same stream folds the table into the 5-int result.
+// (Atomics on the accumulator itself serialise: all workgroups finish together, read the same untouched
+// bounds and then queue ~10^4 atomics on one cache line -- measured +50 us on a 13 us warp.)  The table
+// is CALLER-OWNED: it is the tail of the bbox accumulator (ints ISX_BBOX_HEAD .. ISX_BBOX_INTS of
+// include/isx.h), so calls on different accumulators may overlap freely on one GPU.  The one exception is
+// isx_bbox_nonzero_static at the end of this file, whose table is a library-owned static array.
+#define ISX_BBOX_MAX_BLOCKS ISX_BBOX_PARTIAL_BLOCKS
 
 // EVERY thread of a 256-thread block must call it
-__device__ __forceinline__ void bbox_block_partial(int minx, int miny, int maxx, int maxy) {
+__device__ __forceinline__ void bbox_block_partial(int32_t *__restrict__ partial, int minx, int miny, int maxx,
+                                                   int maxy) {
     __shared__ int red[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int a = wave_min(minx), b = wave_min(miny), c = wave_max(maxx), d = wave_max(maxy);
@@ -130,15 +131,16 @@ __device__ __forceinline__ void bbox_block_partial(int minx, int miny, int maxx,
             x1 = max(x1, red[w][2]);
             y1 = max(y1, red[w][3]);
         }
-        int32_t *o = g_bbox_partial + 4 * blockIdx.x;
+        int32_t *o = partial + 4 * blockIdx.x;
         o[0] = x0, o[1] = y0, o[2] = x1, o[3] = y1;
     }
 }
 
-__global__ void __launch_bounds__(256) bbox_finish_kernel(int n_blocks, int32_t *__restrict__ bb) {
+__global__ void __launch_bounds__(256) bbox_finish_kernel(int n_blocks, const int32_t *__restrict__ partial,
+                                                          int32_t *__restrict__ bb) {
     int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
     for (int i = threadIdx.x; i < n_blocks; i += 256) {
-        const int32_t *o = g_bbox_partial + 4 * i;
+        const int32_t *o = partial + 4 * i;
         x0 = min(x0, o[0]);
         y0 = min(y0, o[1]);
         x1 = max(x1, o[2]);
@@ -189,7 +191,8 @@ __device__ __forceinline__ void bbox_quad(const uint32_t (&px)[4], int x, int y,
 // Tile = 256 pixels x 16 rows (wave w takes rows w, w+4, w+8, w+12; four 768-byte loads in flight).
 template <int C>
 __global__ void __launch_bounds__(256) bbox_nonzero_kernel(const uint8_t *__restrict__ img, int h, int w,
-                                                           int64_t pitch, int tiles_x, int n_tiles) {
+                                                           int64_t pitch, int tiles_x, int n_tiles,
+                                                           int32_t *__restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int minx = INT_MAX, miny = INT_MAX, maxx = -1, maxy = -1;
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -203,16 +206,15 @@ __global__ void __launch_bounds__(256) bbox_nonzero_kernel(const uint8_t *__rest
 #pragma unroll
         for (int i = 0; i < 4; i++) bbox_quad<C>(px[i], x, y0 + 4 * i, minx, miny, maxx, maxy);
     }
-    bbox_block_partial(minx, miny, maxx, maxy);
+    bbox_block_partial(partial, minx, miny, maxx, maxy);
 }
 
-extern "C" int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int64_t pitch, int32_t *bbox_out_dev,
-                                void *stream) {
+int isx_bbox_nonzero_launch(const uint8_t *img_dev, int h, int w, int c, int64_t pitch, int32_t *result_dev,
+                               int32_t *partial_dev, hipStream_t st) {
     ISX_REQUIRE(c == 1 || c == 3, "channels must be 1 or 3 (got %d)", c);
     ISX_REQUIRE(h >= 0 && w >= 0 && pitch >= (int64_t)w * c, "bad image geometry h=%d w=%d pitch=%lld", h, w, (long long)pitch);
-    ISX_REQUIRE(bbox_out_dev, "null bbox_out_dev");
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, bbox_out_dev);
+    ISX_REQUIRE(result_dev && partial_dev, "null bbox accumulator");
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, st, result_dev);
     if (h > 0 && w > 0) {
         ISX_REQUIRE(img_dev, "null img_dev");
         const int tiles_x = (w + 255) / 256;
@@ -220,12 +222,18 @@ extern "C" int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int
         ISX_REQUIRE(n_tiles < ((int64_t)1 << 31), "image too large");
         const unsigned grid = (unsigned)(n_tiles < ISX_BBOX_MAX_BLOCKS ? n_tiles : ISX_BBOX_MAX_BLOCKS);
         if (c == 3)
-            hipLaunchKernelGGL((bbox_nonzero_kernel<3>), dim3(grid), dim3(256), 0, st, img_dev, h, w, pitch, tiles_x, (int)n_tiles);
+            hipLaunchKernelGGL((bbox_nonzero_kernel<3>), dim3(grid), dim3(256), 0, st, img_dev, h, w, pitch, tiles_x, (int)n_tiles, partial_dev);
         else
-            hipLaunchKernelGGL((bbox_nonzero_kernel<1>), dim3(grid), dim3(256), 0, st, img_dev, h, w, pitch, tiles_x, (int)n_tiles);
-        hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(256), 0, st, (int)grid, bbox_out_dev);
+            hipLaunchKernelGGL((bbox_nonzero_kernel<1>), dim3(grid), dim3(256), 0, st, img_dev, h, w, pitch, tiles_x, (int)n_tiles, partial_dev);
+        hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(256), 0, st, (int)grid, partial_dev, result_dev);
     }
     return isx_launch_status("bbox_nonzero_kernel");
+}
+
+extern "C" int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int64_t pitch, int32_t *bbox_out_dev,
+                                void *stream) {
+    ISX_REQUIRE(bbox_out_dev, "null bbox_out_dev");
+    return isx_bbox_nonzero_launch(img_dev, h, w, c, pitch, bbox_out_dev, bbox_out_dev + ISX_BBOX_HEAD, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -369,7 +377,9 @@ __device__ __forceinline__ uint32_t warp_pixel_classic(const uint8_t *__restrict
 // flight per lane, one 12-byte store).  Capped, strided grid; per-block partial bbox (see above).
 template <int C, bool PERSP, bool CLASSIC = false>
 __global__ void __launch_bounds__(256) warp_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst,
-                                                   const WarpParams P, int tiles_x, int n_tiles, int want_bbox) {
+                                                   const WarpParams P, int tiles_x, int n_tiles,
+                                                   int32_t *__restrict__ bbox_partial) {
+    const bool want_bbox = bbox_partial != nullptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int minx = INT_MAX, miny = INT_MAX, maxx = -1, maxy = -1;
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -385,7 +395,7 @@ __global__ void __launch_bounds__(256) warp_kernel(const uint8_t *__restrict__ s
         if (lx < P.dw) quad_store<C>(dst + (int64_t)ly * P.dpitch, lx, P.dw, px);
         if (want_bbox) bbox_quad<C>(px, P.dx0 + lx, P.dy0 + ly, minx, miny, maxx, maxy);
     }
-    if (want_bbox) bbox_block_partial(minx, miny, maxx, maxy);
+    if (want_bbox) bbox_block_partial(bbox_partial, minx, miny, maxx, maxy);
 }
 
 // host-side inverse exactly as cv::warpAffine / cv::warpPerspective compute it (double)
@@ -456,7 +466,7 @@ extern "C" int isx_warp_arith(const uint8_t *src_dev, int sh, int sw, int c, int
     const unsigned nblk = (unsigned)(n_tiles < ISX_BBOX_MAX_BLOCKS ? n_tiles : ISX_BBOX_MAX_BLOCKS);
     dim3 grid(nblk), block(256);
     const bool persp = model == ISX_MODEL_HOMOGRAPHY;
-    const int wb = bbox_out_dev != nullptr;
+    int32_t *const wb = bbox_out_dev ? bbox_out_dev + ISX_BBOX_HEAD : nullptr;
 #define ISX_WARP_LAUNCH(CC, PP, AA) \
     hipLaunchKernelGGL((warp_kernel<CC, PP, AA>), grid, block, 0, st, src_dev, dst_dev, P, tiles_x, n_tiles, wb)
     if (arith == ISX_WARP_CLASSIC) {
@@ -471,7 +481,7 @@ extern "C" int isx_warp_arith(const uint8_t *src_dev, int sh, int sw, int c, int
         else ISX_WARP_LAUNCH(1, false, false);
     }
 #undef ISX_WARP_LAUNCH
-    if (wb) hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(256), 0, st, (int)nblk, bbox_out_dev);
+    if (wb) hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(256), 0, st, (int)nblk, wb, bbox_out_dev);
     return isx_launch_status("warp_kernel");
 }
 
@@ -562,8 +572,10 @@ extern "C" int isx_alpha_blend(const uint8_t *warped_dev, int64_t wpitch, const 
 template <int C, bool PERSP, bool CLASSIC>
 __global__ void __launch_bounds__(256) warp_alpha_kernel(const uint8_t *__restrict__ src, const uint8_t *ref,
                                                          int64_t rpitch, uint8_t *out, int64_t opitch,
-                                                         const WarpParams P, int tiles_x, int n_tiles, int want_bbox,
-                                                         double contrib, double one_minus) {
+                                                         const WarpParams P, int tiles_x, int n_tiles,
+                                                         int32_t *__restrict__ bbox_partial, double contrib,
+                                                         double one_minus) {
+    const bool want_bbox = bbox_partial != nullptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int minx = INT_MAX, miny = INT_MAX, maxx = -1, maxy = -1;
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
@@ -582,7 +594,7 @@ __global__ void __launch_bounds__(256) warp_alpha_kernel(const uint8_t *__restri
         if (lx < P.dw) quad_store<C>(out + (int64_t)ly * opitch, lx, P.dw, po);
         if (want_bbox) bbox_quad<C>(px, P.dx0 + lx, P.dy0 + ly, minx, miny, maxx, maxy);
     }
-    if (want_bbox) bbox_block_partial(minx, miny, maxx, maxy);
+    if (want_bbox) bbox_block_partial(bbox_partial, minx, miny, maxx, maxy);
 }
 
 extern "C" int isx_warp_alpha_blend(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
@@ -623,7 +635,7 @@ extern "C" int isx_warp_alpha_blend(const uint8_t *src_dev, int sh, int sw, int 
     const unsigned nblk = (unsigned)(n_tiles < ISX_BBOX_MAX_BLOCKS ? n_tiles : ISX_BBOX_MAX_BLOCKS);
     dim3 grid(nblk), block(256);
     const bool persp = model == ISX_MODEL_HOMOGRAPHY, classic = arith == ISX_WARP_CLASSIC;
-    const int wb = bbox_out_dev != nullptr;
+    int32_t *const wb = bbox_out_dev ? bbox_out_dev + ISX_BBOX_HEAD : nullptr;
     const double one_minus = 1 - ref_contrib;
 #define ISX_WA_LAUNCH(CC, PP, AA)                                                                                    \
     hipLaunchKernelGGL((warp_alpha_kernel<CC, PP, AA>), grid, block, 0, st, src_dev, ref_dev, rpitch, out_dev, opitch, P, \
@@ -640,7 +652,7 @@ extern "C" int isx_warp_alpha_blend(const uint8_t *src_dev, int sh, int sw, int 
         else ISX_WA_LAUNCH(1, false, false);
     }
 #undef ISX_WA_LAUNCH
-    if (wb) hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(256), 0, st, (int)nblk, bbox_out_dev);
+    if (wb) hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(256), 0, st, (int)nblk, wb, bbox_out_dev);
     return isx_launch_status("warp_alpha_kernel");
 }
 

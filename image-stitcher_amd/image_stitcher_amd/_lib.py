@@ -12,6 +12,8 @@ WARP_LINEAR_F32, WARP_CLASSIC = 0, 1  # enum isx_warp_arith
 MODEL_AFFINE_PARTIAL, MODEL_HOMOGRAPHY = 0, 1
 BLEND_ALPHA, BLEND_GRADIENT = 0, 1
 L2_EXACT_LIMIT = 4197200
+BBOX_PARTIAL_BLOCKS, BBOX_HEAD = 2048, 8
+BBOX_INTS = BBOX_HEAD + 4 * BBOX_PARTIAL_BLOCKS  # include/isx.h ISX_BBOX_INTS
 
 c_void_p, c_int, c_int64, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
 

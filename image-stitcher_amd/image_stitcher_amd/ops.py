@@ -383,13 +383,15 @@ def _img_args(t, name="image"):
     return _ptr(t), h, w, c, pitch
 
 
-def bbox_nonzero(img):
-    """get_corners_from_image on the device: int32[5] tensor {x0,y0,x1,y1,found} (no sync)."""
+def bbox_nonzero(img, acc=None):
+    """get_corners_from_image on the device: int32[5] tensor {x0,y0,x1,y1,found} (no sync).  acc: optional
+    accumulator from new_bbox() to reuse (the result is its first 5 ints)."""
     p, h, w, c, pitch = _img_args(img)
     with torch.cuda.device(img.device):
-        bb = torch.empty((5,), dtype=torch.int32, device=img.device)
-        check(_lib.lib().isx_bbox_nonzero(p, h, w, c, pitch, _ptr(bb), _stream()))
-    return bb
+        if acc is None:
+            acc = torch.empty((_lib.BBOX_INTS,), dtype=torch.int32, device=img.device)
+        check(_lib.lib().isx_bbox_nonzero(p, h, w, c, pitch, _ptr(acc), _stream()))
+    return acc[:5]
 
 
 def bbox_to_corners(bb_host):
@@ -405,7 +407,7 @@ WARP_ARITH = {"f32": _lib.WARP_LINEAR_F32, "classic": _lib.WARP_CLASSIC}
 def warp(src, M, perspective, dst_rect, src_xy=(0, 0), out=None, bbox=None, arith="f32", canvas=None):
     """cv2.warpAffine / cv2.warpPerspective (INTER_LINEAR, constant 0) of `src` placed at src_xy of a
     virtual canvas, producing canvas rectangle dst_rect = (x0, y0, w, h).  M: forward 2x3 / 3x3 float64.
-    bbox: optional int32[5] accumulator tensor (gray != 0 bbox of the produced pixels).
+    bbox: optional accumulator from new_bbox() (gray != 0 bbox of the produced pixels in its first 5 ints).
     arith: "f32" = OpenCV 4.11's float32 linear kernels (the reference's pinned version), "classic" = the
     1/32-px fixed-point remap of OpenCV <= 4.10; canvas = (W, H) of the full destination, needed by the
     classic perspective path (defaults to the extent of dst_rect)."""
@@ -459,8 +461,10 @@ def warp_alpha_blend(src, M, perspective, dst_rect, ref, contrib, src_xy=(0, 0),
 
 
 def new_bbox(device):
+    """A bbox accumulator (include/isx.h: ISX_BBOX_INTS int32 -- 5 result ints, then the caller-owned partial
+    table the reduction kernels use), reset.  Read the result as acc[:5]."""
     with torch.cuda.device(device):
-        bb = torch.empty((5,), dtype=torch.int32, device=device)
+        bb = torch.empty((_lib.BBOX_INTS,), dtype=torch.int32, device=device)
         check(_lib.lib().isx_bbox_reset(_ptr(bb), _stream()))
     return bb
 

@@ -489,7 +489,7 @@ class Stitcher:
                 wbuf = torch.empty((qh, qw) + shape_c, dtype=torch.uint8, device=dev)
                 ops.warp(img_d.t, M, self.type == 1, (qx0, qy0, qw, qh), src_xy=(ox, oy), out=wbuf, bbox=wbb,
                          arith=self.warp_arith, canvas=(W, H))
-                wcorners = ops.bbox_to_corners(wbb.cpu().numpy())
+                wcorners = ops.bbox_to_corners(wbb[:5].cpu().numpy())
                 if qw and qh and wcorners is not False:
                     # seamless_gradient_merge ROI: bbox(warped) +- 50 clipped to the canvas (proc.py:199-205)
                     gx0, gy0 = max(0, wcorners[0][0] - 50), max(0, wcorners[0][1] - 50)
@@ -498,7 +498,7 @@ class Stitcher:
                                            U[gy0 - uy0:gy1 - uy0, gx0 - ux0:gx1 - ux0])
             mb = ops.bbox_nonzero(U).cpu().numpy()
             if wcorners is None:
-                wcorners = ops.bbox_to_corners(wbb.cpu().numpy())
+                wcorners = ops.bbox_to_corners(wbb[:5].cpu().numpy())
 
         if self.consecutive_range is not None:
             corners = wcorners

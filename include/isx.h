@@ -15,10 +15,8 @@
  *     the call returns without synchronising unless stated otherwise;
  *   - every function returns 0 on success or a negative isx_status; isx_last_error() returns a
  *     thread-local human readable message for the last failure on the calling thread;
- *   - calls may be issued from any thread and on any stream, with one exception: the entry points that
- *     take a bbox accumulator (`bbox_out_dev`, `bbox_dev`) reduce through one library-owned per-device
- *     table, so two such calls must not be in flight on the same GPU at once (issue them on one stream,
- *     or order them by events);
+ *   - calls may be issued from any thread and on any stream; the library keeps no device state between
+ *     calls;
  *   - there is no CPU fallback: without a HIP device the compute entry points fail with ISX_E_HIP.
  */
 #ifndef ISX_H
@@ -151,9 +149,16 @@ int isx_ratio_compact(const int32_t *idx_dev, const float *dist_dev, int nq, dou
  * stride in bytes, so a crop / ROI of a device image is a pointer to its first pixel + the parent pitch.
  * ------------------------------------------------------------------------------------------------ */
 
+/* A bbox ACCUMULATOR is ISX_BBOX_INTS int32 of caller-owned device memory: ints 0..4 are the result
+ * {x0, y0, x1, y1 (exclusive), found}, ints ISX_BBOX_HEAD.. are the per-workgroup partial table the reduction
+ * kernels use as scratch (caller-owned, so bbox-producing calls on different accumulators may overlap on one GPU). */
+#define ISX_BBOX_PARTIAL_BLOCKS 2048
+#define ISX_BBOX_HEAD 8
+#define ISX_BBOX_INTS (ISX_BBOX_HEAD + 4 * ISX_BBOX_PARTIAL_BLOCKS)
+
 /* Replaces get_corners_from_image (utils/proc.py:34-45: cv2.cvtColor(BGR2GRAY) -> cv2.findNonZero ->
  * cv2.boundingRect), also the bbox half of crop_image (utils/proc.py:307-312).
- * bbox_out_dev: 5 int32 {x0, y0, x1, y1 (exclusive), found}; found == 0 <=> the reference returns False. */
+ * bbox_out_dev: a bbox accumulator (ISX_BBOX_INTS int32); found == 0 <=> the reference returns False. */
 int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int64_t pitch, int32_t *bbox_out_dev,
                      void *stream);
 /* Re-initialise a bbox accumulator (for isx_warp's accumulating bbox output). */
@@ -164,7 +169,7 @@ int isx_bbox_reset(int32_t *bbox_dev, void *stream);
  * sitting at (src_x, src_y) of the virtual padded canvas of get_padded_images (utils/proc.py:295-304).
  * Produces only the canvas rectangle [dx0,dx0+dw) x [dy0,dy0+dh) into dst_dev (its first pixel).
  *   M_host : forward map, 6 doubles (model ISX_MODEL_AFFINE_PARTIAL, 2x3) or 9 doubles (3x3)
- *   bbox_out_dev : optional 5-int accumulator (see isx_bbox_reset) that receives the bbox, in canvas
+ *   bbox_out_dev : optional bbox accumulator (ISX_BBOX_INTS int32, see isx_bbox_reset) that receives the bbox, in canvas
  *                  coordinates, of produced pixels whose gray != 0  (stitcher.py:220) */
 int isx_warp(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
              const double *M_host, int model, uint8_t *dst_dev, int64_t dpitch, int dx0, int dy0, int dw,

@@ -262,3 +262,29 @@ def test_fused_warp_alpha_blend(cuda, orc, c, persp, arith):
         # outside the rectangle warped is 0: blend(0, ref) = ref there (no overlap, 0 + ref), so the whole canvas matches
         assert np.array_equal(got, exp), f"{(got != exp).sum()} pixels differ"
         assert ops.bbox_to_corners(bb.cpu().numpy()) == orc.bbox_nonzero(warped)
+
+
+def test_bbox_calls_overlap_on_two_streams(cuda, orc):
+    """Every bbox accumulator carries its own partial table (include/isx.h ISX_BBOX_INTS), so bbox-producing
+    calls on different accumulators may be in flight on one GPU at once: many rounds of two different images
+    reduced concurrently on two streams give each image its own box."""
+    import torch
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(5)
+    a = np.zeros((2100, 3900, 3), np.uint8)
+    b = np.zeros((1900, 4100, 3), np.uint8)
+    a[300:1500, 700:3000] = rng.integers(1, 255, (1200, 2300, 3), dtype=np.uint8)
+    b[40:1800, 90:4000] = rng.integers(1, 255, (1760, 3910, 3), dtype=np.uint8)
+    da, db = dev(a), dev(b)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    acc1, acc2 = ops.new_bbox(cuda), ops.new_bbox(cuda)
+    torch.cuda.synchronize()
+    res = []
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            r1 = ops.bbox_nonzero(da, acc=acc1)
+        with torch.cuda.stream(s2):
+            r2 = ops.bbox_nonzero(db, acc=acc2)
+        torch.cuda.synchronize()
+        res.append((ops.bbox_to_corners(r1.cpu().numpy()), ops.bbox_to_corners(r2.cpu().numpy())))
+    assert all(r == (orc.bbox_nonzero(a), orc.bbox_nonzero(b)) for r in res)

@@ -29,7 +29,7 @@ int main() {
     CK(hipMalloc(&src, h.size())); CK(hipMemcpy(src, h.data(), h.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&wbuf, (size_t)dw * dh * C)); CK(hipMalloc(&roi, (size_t)dw * dh * C));
     CK(hipMemset(roi, 90, (size_t)dw * dh * C));
-    CK(hipMalloc(&bb, 5 * 4)); CK(hipMalloc(&ext, (2 * dh + 2 * dw) * 4));
+    CK(hipMalloc(&bb, ISX_BBOX_INTS * 4)); CK(hipMalloc(&ext, (2 * dh + 2 * dw) * 4));
     const double M[6] = {0.9998, -0.0175, 300.0, 0.0175, 0.9998, 12.0};
     const int sx = 1920, sy = 1080, dx0 = 1920 + 250, dy0 = 1080 - 40;
     const double src_b = (double)sh * sw * C, roi_b = (double)dw * dh * C;
