@@ -4,6 +4,9 @@ reference's cv2 SIFT/ORB so both paths see identical descriptors"; reference sti
   make_detector(algorithm)  -> cv2.SIFT_create() / ORB_create() / AKAZE_create() when cv2 is importable
   NumpyOrbLite              -> a small numpy/scipy corner + BRIEF-style detector used by the tests and
                                bench.py where cv2 is not installed (it is NOT part of the hot path)
+  NumpySiftLite             -> the same corners with a 4x4x8 gradient-histogram descriptor post-processed like
+                               cv2.SIFT's (normalise, clip 0.2, renormalise, x512, round): 128-d float32 that is
+                               INTEGER VALUED in [0,255], the property the exact int8 matcher relies on
 Any object with detectAndCompute(image, mask) -> (keypoints, descriptors) can be passed to the stitchers
 as `detector=`; keypoints need a mutable `.pt` (x, y) like cv2.KeyPoint.
 """
@@ -46,14 +49,15 @@ class NumpyOrbLite:
         p = np.clip(np.rint(rng.normal(0, patch / 2.2, (256, 4))), -patch, patch).astype(np.int32)
         self.pairs = p
 
-    def detectAndCompute(self, image, mask=None):
+    def _corners(self, image):
+        """Harris corners away from black (padding) regions -> (blurred float32 image, ys, xs, responses) or None"""
         from scipy import ndimage
         img = np.asarray(image)
         g8 = _gray(img)
         h, w = g8.shape
         m = self.patch + 4
         if h <= 2 * m + 2 or w <= 2 * m + 2:
-            return [], None
+            return None
         g = ndimage.gaussian_filter(g8.astype(np.float32), 2.0)
         ix = ndimage.sobel(g, axis=1)
         iy = ndimage.sobel(g, axis=0)
@@ -71,13 +75,51 @@ class NumpyOrbLite:
         peak = (r == ndimage.maximum_filter(r, size=self.nms)) & (r > 1e-6 * max(float(r.max()), 1e-30))
         ys, xs = np.nonzero(peak)
         if len(xs) == 0:
-            return [], None
+            return None
         resp = r[ys, xs]
         order = np.argsort(-resp, kind="stable")[: self.nfeatures]
-        ys, xs, resp = ys[order], xs[order], resp[order]
+        return g, ys[order], xs[order], resp[order], ix, iy
+
+    def detectAndCompute(self, image, mask=None):
+        found = self._corners(image)
+        if found is None:
+            return [], None
+        g, ys, xs, resp = found[:4]
         p = self.pairs
         a = g[ys[:, None] + p[None, :, 1], xs[:, None] + p[None, :, 0]]
         b = g[ys[:, None] + p[None, :, 3], xs[:, None] + p[None, :, 2]]
         des = np.packbits(a < b, axis=1)
+        kps = [KeyPoint(x, y, v) for x, y, v in zip(xs, ys, resp)]
+        return kps, des
+
+
+class NumpySiftLite(NumpyOrbLite):
+    """Same corners; descriptor = 4x4 cells x 8 orientation bins of gradient magnitude over a 16x16 window,
+    then cv2.SIFT's post-processing -> (n,128) float32, integer valued in [0,255], ||d|| ~ 512.  Stand-in for
+    cv2.SIFT_create() (BASELINE configs[0], algorithm=0) where cv2 is not installed; NOT part of the hot path."""
+
+    def __init__(self, nfeatures=1500, seed=7, nms=7):
+        super().__init__(nfeatures=nfeatures, patch=12, seed=seed, nms=nms)
+        d = np.arange(-8, 8)
+        self._dy, self._dx = (a.reshape(-1) for a in np.meshgrid(d, d, indexing="ij"))
+        self._cell = (((self._dy + 8) // 4) * 4 + (self._dx + 8) // 4) * 8
+
+    def detectAndCompute(self, image, mask=None):
+        found = self._corners(image)
+        if found is None:
+            return [], None
+        g, ys, xs, resp, ix, iy = found
+        py, px = ys[:, None] + self._dy[None, :], xs[:, None] + self._dx[None, :]
+        gx, gy = ix[py, px], iy[py, px]
+        mag = np.sqrt(gx * gx + gy * gy)
+        ori = (np.floor((np.arctan2(gy, gx) + np.pi) * (8 / (2 * np.pi))).astype(np.int64)) % 8
+        n = len(xs)
+        flat = (np.arange(n)[:, None] * 128 + self._cell[None, :] + ori).reshape(-1)
+        hist = np.bincount(flat, weights=mag.reshape(-1).astype(np.float64), minlength=n * 128).reshape(n, 128)
+        hist = hist.astype(np.float32)
+        hist /= np.maximum(np.linalg.norm(hist, axis=1, keepdims=True), 1e-12)
+        np.minimum(hist, 0.2, out=hist)
+        hist /= np.maximum(np.linalg.norm(hist, axis=1, keepdims=True), 1e-12)
+        des = np.clip(np.rint(hist * 512.0), 0, 255).astype(np.float32)
         kps = [KeyPoint(x, y, v) for x, y, v in zip(xs, ys, resp)]
         return kps, des
