@@ -39,6 +39,7 @@ SIGNATURES = {
     "isx_ratio_compact": (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isx_bbox_nonzero": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "isx_bbox_reset": (c_int, [c_void_p, c_void_p]),
+    "isx_bbox_nonzero_static": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "isx_warp": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64,
                          c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "isx_warp_arith": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64,

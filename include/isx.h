@@ -164,6 +164,16 @@ int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int64_t pitch,
 /* Re-initialise a bbox accumulator (for isx_warp's accumulating bbox output). */
 int isx_bbox_reset(int32_t *bbox_dev, void *stream);
 
+/* isx_bbox_nonzero for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  bbox_out_dev is just
+ * the 5-int result {x0, y0, x1, y1, found}; the partial table is a static device array inside the library
+ * (32 KiB per GPU, held until the process ends), so the entry point allocates nothing and needs no workspace.
+ * Limits: h, w <= ISX_BBOX_STATIC_MAX_DIM (larger images are refused with ISX_E_ARG); the image's device
+ * must be current and own `stream`; calls that overlap on one GPU race on the shared array. */
+#define ISX_BBOX_STATIC_MAX_DIM 65536
+int isx_bbox_nonzero_static(const uint8_t *img_dev, int h, int w, int c, int64_t pitch, int32_t *bbox_out_dev,
+                            void *stream);
+
 /* Replaces Stitcher.warp_target (stitcher.py:143-149: cv2.warpAffine / cv2.warpPerspective with
  * INTER_LINEAR, BORDER_CONSTANT 0, dsize = padded canvas) for a source that is the UN-padded frame
  * sitting at (src_x, src_y) of the virtual padded canvas of get_padded_images (utils/proc.py:295-304).
