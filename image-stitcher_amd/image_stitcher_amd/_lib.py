@@ -12,6 +12,7 @@ WARP_LINEAR_F32, WARP_CLASSIC = 0, 1  # enum isx_warp_arith
 MODEL_AFFINE_PARTIAL, MODEL_HOMOGRAPHY = 0, 1
 BLEND_ALPHA, BLEND_GRADIENT = 0, 1
 L2_EXACT_LIMIT = 4197200
+FRAME_RESULT_INTS = 32
 BBOX_PARTIAL_BLOCKS, BBOX_HEAD = 2048, 8
 BBOX_INTS = BBOX_HEAD + 4 * BBOX_PARTIAL_BLOCKS  # include/isx.h ISX_BBOX_INTS
 
@@ -51,6 +52,12 @@ SIGNATURES = {
                                 c_double, c_void_p]),
     "isx_gradient_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p]),
+    "isx_ctx_create": (c_int, [c_void_p]),
+    "isx_ctx_destroy": (c_int, [c_void_p]),
+    "isx_frame_blend": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_int,
+                                c_int, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int, c_double,
+                                c_int, c_void_p, c_void_p]),
+    "isx_frame_warped": (c_int, [c_void_p, c_void_p]),
     "isx_copy2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_void_p]),
     "isx_ransac_sample": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "isx_ransac_hypotheses": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -5,8 +5,9 @@ mosaic).
 AsyncImageWriter.submit() snapshots a resident mosaic into pinned host memory on a side HIP stream (the
 stitching stream only records an event) and hands it to ONE worker thread that waits for the copy, applies
 the user's blend_processor and encodes the file.  One worker = files appear in submission order; flush()
-returns when everything submitted so far is on disk.  Mosaics are immutable once published (every stitch
-builds a new canvas), so the snapshot equals what the synchronous path would have written.
+returns when everything submitted so far is on disk.  Resident mosaics are blended in place by later stitches,
+so the stitching stream is made to wait (GPU side) for the snapshot copy: the file equals what the synchronous
+path would have written.
 """
 import atexit
 import os
@@ -60,6 +61,9 @@ class AsyncImageWriter:
                 ev = torch.cuda.Event()
                 ev.record(self._stream)
             t.record_stream(self._stream)
+            # resident mosaics are blended in place by the next stitch: later work on the stitching stream
+            # waits (on the GPU, not the host) until the snapshot has been taken
+            cur.wait_stream(self._stream)
             self._q.put((ev, buf, host, filepath, processor))
         else:
             self._q.put((None, None, np.array(np.asarray(t), copy=True), filepath, processor))

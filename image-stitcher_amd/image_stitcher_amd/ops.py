@@ -504,6 +504,78 @@ def gradient_blend_roi(warped_roi, ref_roi, feather=10, ext=None):
     return ref_roi
 
 
+class FrameCtx:
+    """isx_ctx (include/isx.h): the per-device workspace of the per-frame pipeline."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(_lib.lib().isx_ctx_create(ctypes.byref(h)))
+        self._h = h
+        self._res = np.zeros((_lib.FRAME_RESULT_INTS,), np.int32)
+        self._old = np.zeros((4,), np.int32)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().isx_ctx_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
+
+
+def frame_blend(ctx, src, M, perspective, src_xy, canvas_wh, arena_t, canvas_to_arena, q_rect, old_bbox, blender,
+                contrib=0.5, feather=10, arith="f32"):
+    """isx_frame_blend: warp `src` (pasted at src_xy of the virtual canvas) by M and blend it IN PLACE into the
+    mosaic held by arena_t (canvas (X, Y) is arena pixel (X + canvas_to_arena[0], Y + canvas_to_arena[1])), only over
+    the canvas rectangle q_rect = (x0, y0, w, h).  old_bbox: (x0,y0,x1,y1) canvas bbox of the mosaic's gray != 0
+    pixels or None.  Synchronous; returns the int32 result block as a dict of python ints / tuples."""
+    p, sh, sw, c, spitch = _img_args(src, "src")
+    pa, ah, aw, ac, apitch = _img_args(arena_t, "arena")
+    if ac != c:
+        raise IsxError("arena and frame differ in channels")
+    qx0, qy0, qw, qh = (int(v) for v in q_rect)
+    ax0, ay0 = qx0 + int(canvas_to_arena[0]), qy0 + int(canvas_to_arena[1])
+    if qw > 0 and qh > 0 and (ax0 < 0 or ay0 < 0 or ax0 + qw > aw or ay0 + qh > ah):
+        raise IsxError("frame_blend: Q lies outside the arena")
+    M = np.ascontiguousarray(M, np.float64)
+    if M.shape != ((3, 3) if perspective else (2, 3)):
+        raise IsxError(f"M has shape {M.shape}")
+    if old_bbox:
+        ctx._old[:] = old_bbox
+        ob = ctx._old.ctypes.data_as(ctypes.c_void_p)
+    else:
+        ob = None
+    mq = ctypes.c_void_p(arena_t.data_ptr() + ay0 * apitch + ax0 * c)
+    r = ctx._res
+    with torch.cuda.device(src.device):
+        check(_lib.lib().isx_frame_blend(ctx._h, p, sh, sw, c, spitch, int(src_xy[0]), int(src_xy[1]),
+                                         M.ctypes.data_as(ctypes.c_void_p),
+                                         _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL,
+                                         WARP_ARITH[arith], int(canvas_wh[0]), int(canvas_wh[1]), mq, apitch, qx0, qy0, qw, qh,
+                                         ob, int(blender), float(contrib), int(feather),
+                                         r.ctypes.data_as(ctypes.c_void_p), _stream()))
+    v = r.tolist()
+    return {"wbbox": tuple(v[0:4]) if v[4] else False, "roi": tuple(v[5:9]), "mbbox": tuple(v[9:13]), "mfound": bool(v[13]),
+            "zeroed": v[14], "dirty": v[15], "rows_ok": bool(v[16]), "done": bool(v[17])}
+
+
+def frame_warped_view(ctx, q_rect, c, ndim3):
+    """The warped image staged by the last gradient-path frame_blend, as a uint8 tensor view of Q's shape."""
+    out = ctypes.c_void_p()
+    check(_lib.lib().isx_frame_warped(ctx._h, ctypes.byref(out)))
+    qw, qh = int(q_rect[2]), int(q_rect[3])
+    n = qw * qh * c
+
+    class _Raw:  # __cuda_array_interface__ holder
+        pass
+    raw = _Raw()
+    raw.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (out.value, False), "version": 2}
+    t = torch.as_tensor(raw, device=ctx.device)
+    return t.view((qh, qw, c) if ndim3 else (qh, qw))
+
+
 def copy2d(src, dst):
     ps, h, w, c, sp = _img_args(src, "src")
     pd, h2, w2, c2, dp = _img_args(dst, "dst")

@@ -26,7 +26,7 @@ import torch
 from . import ops
 from .async_save import AsyncImageWriter, write_image
 from .detect import make_detector
-from .device_image import DeviceImage
+from .device_image import DeviceImage, MosaicArena
 from .pairs import components_from_counts, directed_items, gather_counts, shard_pairs, unordered_pairs
 from .utils.logger import LogWrapper
 from .utils.proc import (crop_image, get_corners_from_image, get_padded_images, get_roi_from_corners,  # noqa: F401
@@ -173,6 +173,9 @@ class Stitcher:
             self._detector, self._detector_b = detector
         self._pool = None
         self._writer = None
+        self._ctx = None          # ops.FrameCtx, created on first use
+        self._inplace_ok = False  # set by the internal callers that replace the reference mosaic by the result
+        self.frame_stats = {"frames": 0, "rows_slow": 0, "rescans": 0, "clears": 0, "arena_allocs": 0}  # diagnostics
 
     # ---- plumbing -------------------------------------------------------------------------------
     @property
@@ -374,6 +377,91 @@ class Stitcher:
         y1 = int(np.ceil(xy[:, 1].max())) + 3 + margin
         return max(0, x0), max(0, y0), min(W, x1), min(H, y1)
 
+    def _frame_ctx(self):
+        if self._ctx is None:
+            self._ctx = ops.FrameCtx(self._dev())
+        return self._ctx
+
+    def _blend_resident(self, img_d, ref_d, M, W, H, rox, roy, ox, oy):
+        """stitcher.py:216-225 (warp_target, merge, corners of the warped image, crop_image) on a resident
+        mosaic arena through ONE library call (ops.frame_blend -> isx_frame_blend).  Coordinates are those of the
+        reference's padded canvas (W x H, mosaic pasted at (rox, roy), frame at (ox, oy)); the canvas itself is
+        never built.  Returns (mosaic DeviceImage | None, corners-of-warped | False)."""
+        ih, iw = img_d.shape[:2]
+        rh, rw = ref_d.shape[:2]
+        C = img_d.channels
+        arena = ref_d._arena
+        live = (arena is not None and self._inplace_ok and (arena.h, arena.w) == (rh, rw) and arena.t.device == ref_d.t.device
+                and arena.view().data_ptr() == ref_d.t.data_ptr())
+        if not live:
+            # a host image, a plain tensor, or a mosaic the caller may still want untouched: start a new arena
+            # shaped like the reference's canvas, so the first frame always fits
+            arena = MosaicArena.around(ref_d.t, iw, ih)
+            self.frame_stats["arena_allocs"] += 1
+        if arena.bbox is None:
+            bb = ops.bbox_nonzero(arena.view())[:5].cpu().numpy()
+            arena.bbox = (int(bb[0]) + arena.x, int(bb[1]) + arena.y, int(bb[2]) + arena.x, int(bb[3]) + arena.y) if bb[4] else False
+        qx0, qy0, qx1, qy1 = self._quad_region(M, ox, oy, iw, ih, W, H, 52)
+        qw, qh = max(0, qx1 - qx0), max(0, qy1 - qy0)
+        if qw == 0 or qh == 0:
+            qx0 = qy0 = qw = qh = 0
+        cax, cay = arena.x - rox, arena.y - roy  # canvas -> arena
+        if qw:
+            t_before = arena.t
+            dx, dy = arena.ensure(qx0 + cax, qy0 + cay, qx0 + qw + cax, qy0 + qh + cay, max(iw, arena.t.shape[1] // 2), max(ih, arena.t.shape[0] // 2))
+            cax, cay = cax + dx, cay + dy
+            self.frame_stats["arena_allocs"] += arena.t is not t_before
+        old = arena.bbox
+        old_c = (old[0] - cax, old[1] - cay, old[2] - cax, old[3] - cay) if old else None
+        res = ops.frame_blend(self._frame_ctx(), img_d.t, M, self.type == 1, (ox, oy), (W, H), arena.t, (cax, cay),
+                              (qx0, qy0, qw, qh), old_c, self.blender, self.ref_image_contrib, 10, self.warp_arith)
+        wb = res["wbbox"]
+        wcorners = ((wb[0], wb[1]), (wb[2], wb[3])) if wb else False
+        written = None  # canvas rectangle whose mosaic pixels were rewritten
+        rescan = False
+        if self.blender == 0:
+            written = (qx0, qy0, qx0 + qw, qy0 + qh) if qw else None
+        elif wb:
+            written = res["roi"]
+            if not res["done"]:
+                # rows_ok == 0 (a channel-0-only pixel far outside the warped image's gray box): the extents of
+                # utils/proc.py:213-218 have to be taken inside the ROI -- the four-kernel blender does that
+                gx0, gy0, gx1, gy1 = written
+                wv = ops.frame_warped_view(self._frame_ctx(), (qx0, qy0, qw, qh), C, img_d.ndim == 3)
+                ops.gradient_blend_roi(wv[gy0 - qy0:gy1 - qy0, gx0 - qx0:gx1 - qx0],
+                                       arena.t[gy0 + cay:gy1 + cay, gx0 + cax:gx1 + cax])
+                rescan = True
+                self.frame_stats["rows_slow"] += 1
+        self.frame_stats["frames"] += 1
+        # the rectangle that can hold non-zero bytes now: the old mosaic's and what was written (arena coordinates)
+        ux0, uy0, ux1, uy1 = arena.x, arena.y, arena.x + arena.w, arena.y + arena.h
+        if written is not None:
+            ux0, uy0 = min(ux0, written[0] + cax), min(uy0, written[1] + cay)
+            ux1, uy1 = max(ux1, written[2] + cax), max(uy1, written[3] + cay)
+        if rescan or res["zeroed"]:
+            self.frame_stats["rescans"] += 1
+            bb = ops.bbox_nonzero(arena.t[uy0:uy1, ux0:ux1])[:5].cpu().numpy()
+            new = (int(bb[0]) + ux0, int(bb[1]) + uy0, int(bb[2]) + ux0, int(bb[3]) + uy0) if bb[4] else False
+        else:
+            mb = res["mbbox"]
+            if old:
+                new = (min(old[0], mb[0] + cax) if mb[0] < 2 ** 30 else old[0], min(old[1], mb[1] + cay) if mb[1] < 2 ** 30 else old[1],
+                       max(old[2], mb[2] + cax) if mb[2] >= 0 else old[2], max(old[3], mb[3] + cay) if mb[3] >= 0 else old[3])
+            else:
+                new = (mb[0] + cax, mb[1] + cay, mb[2] + cax, mb[3] + cay) if res["mfound"] else False
+        if new is False:
+            return None, wcorners
+        if arena.dirty or res["dirty"] or rescan or res["zeroed"]:
+            # bytes of gray == 0 pixels outside the crop: the reference's crop drops them
+            for (y0, y1, x0, x1) in ((uy0, new[1], ux0, ux1), (new[3], uy1, ux0, ux1), (new[1], new[3], ux0, new[0]),
+                                     (new[1], new[3], new[2], ux1)):
+                if y1 > y0 and x1 > x0:
+                    arena.t[y0:y1, x0:x1] = 0
+                    self.frame_stats["clears"] += 1
+        arena.x, arena.y, arena.w, arena.h = new[0], new[1], new[2] - new[0], new[3] - new[1]
+        arena.bbox, arena.dirty = new, False
+        return DeviceImage(arena.view(), arena=arena), wcorners
+
     def _overridden(self, name):
         """True when a subclass replaced one of the reference's seam methods (stitcher.py:106-165)."""
         return getattr(type(self), name) is not getattr(Stitcher, name)
@@ -468,37 +556,7 @@ class Stitcher:
             return self._stitch_tail_via_seams(img_d, ref_d, M, tf)
 
         with torch.cuda.device(dev):
-            # warped frame, only where it can be non-zero (+52 px so that the gradient ROI fits)
-            qx0, qy0, qx1, qy1 = self._quad_region(M, ox, oy, iw, ih, W, H, 52)
-            qw, qh = max(0, qx1 - qx0), max(0, qy1 - qy0)
-            shape_c = (C,) if img_d.ndim == 3 else ()
-            wbb = ops.new_bbox(dev)
-            # merged canvas restricted to U = bounding rectangle of (ref, warped region)
-            ux0, uy0 = min(rox, qx0) if qw and qh else rox, min(roy, qy0) if qw and qh else roy
-            ux1, uy1 = max(rox + rw, qx1) if qw and qh else rox + rw, max(roy + rh, qy1) if qw and qh else roy + rh
-            U = torch.zeros((uy1 - uy0, ux1 - ux0) + shape_c, dtype=torch.uint8, device=dev)
-            ops.copy2d(ref_d.t, U[roy - uy0:roy - uy0 + rh, rox - ux0:rox - ux0 + rw])
-            if self.blender == 0:
-                # alpha blender: warp + merge fused in one pass over the region, in place on U
-                if qw and qh:
-                    uq = U[qy0 - uy0:qy1 - uy0, qx0 - ux0:qx1 - ux0]
-                    ops.warp_alpha_blend(img_d.t, M, self.type == 1, (qx0, qy0, qw, qh), uq, self.ref_image_contrib,
-                                         src_xy=(ox, oy), bbox=wbb, arith=self.warp_arith, canvas=(W, H))
-                wcorners = None  # read back together with the merged bbox below
-            else:
-                wbuf = torch.empty((qh, qw) + shape_c, dtype=torch.uint8, device=dev)
-                ops.warp(img_d.t, M, self.type == 1, (qx0, qy0, qw, qh), src_xy=(ox, oy), out=wbuf, bbox=wbb,
-                         arith=self.warp_arith, canvas=(W, H))
-                wcorners = ops.bbox_to_corners(wbb[:5].cpu().numpy())
-                if qw and qh and wcorners is not False:
-                    # seamless_gradient_merge ROI: bbox(warped) +- 50 clipped to the canvas (proc.py:199-205)
-                    gx0, gy0 = max(0, wcorners[0][0] - 50), max(0, wcorners[0][1] - 50)
-                    gx1, gy1 = min(W, wcorners[1][0] + 50), min(H, wcorners[1][1] + 50)
-                    ops.gradient_blend_roi(wbuf[gy0 - qy0:gy1 - qy0, gx0 - qx0:gx1 - qx0],
-                                           U[gy0 - uy0:gy1 - uy0, gx0 - ux0:gx1 - ux0])
-            mb = ops.bbox_nonzero(U).cpu().numpy()
-            if wcorners is None:
-                wcorners = ops.bbox_to_corners(wbb[:5].cpu().numpy())
+            mosaic, wcorners = self._blend_resident(img_d, ref_d, M, W, H, rox, roy, ox, oy)
 
         if self.consecutive_range is not None:
             corners = wcorners
@@ -506,9 +564,8 @@ class Stitcher:
                 self.logger.warning("Could not get image corners. The merged image has no non-black regions.")
                 corners = None
 
-        if not mb[4]:
+        if mosaic is None:
             return None  # crop_image returned False (stitcher.py:226-227)
-        mosaic = DeviceImage(U[int(mb[1]):int(mb[3]), int(mb[0]):int(mb[2])])
         if not self.resident:
             mosaic = np.ascontiguousarray(mosaic.numpy())
         return mosaic, corners, tf
@@ -630,7 +687,11 @@ class ArbitraryStitcher(Stitcher):
                 remove_indexes = list()
                 corners = None
                 for k in idxs:
-                    result = self.stitch(reference_image, self.images[k], corners=corners)
+                    self._inplace_ok = True  # reference_image is replaced by the result below
+                    try:
+                        result = self.stitch(reference_image, self.images[k], corners=corners)
+                    finally:
+                        self._inplace_ok = False
                     if result is False:
                         unblended_collections.append(idxs[k:])
                         key_points_broken = True
@@ -695,6 +756,13 @@ class ConsecutiveStitcher(Stitcher):
                 self.save_last_stitch()
         return tf
 
+    def _stitch_inplace(self, ref, image, **kw):
+        self._inplace_ok = True
+        try:
+            return self.stitch(ref, image, **kw)
+        finally:
+            self._inplace_ok = False
+
     @timer
     def stitch_consecutive(self, input_image, tf=None):
         """stitcher.py:416-439: returns the TransformDetails on success, the caller's `tf` otherwise."""
@@ -703,11 +771,12 @@ class ConsecutiveStitcher(Stitcher):
         if self.refs[-1] is None:
             self.refs[-1] = image
         else:
-            result = self.stitch(self.refs[-1], image, corners=self.corners, tf=tf)
+            # refs[-1] / exref are replaced by the result on success, so the resident mosaic is blended in place
+            result = self._stitch_inplace(self.refs[-1], image, corners=self.corners, tf=tf)
             if result is False or result is None:
                 if self.current_image_count < self.consecutive_volatility_threshold:
                     for exref in reversed(self.refs[:-1]):
-                        result = self.stitch(exref, image, corners=self.corners, tf=tf)
+                        result = self._stitch_inplace(exref, image, corners=self.corners, tf=tf)
                         if not (result is False or result is None):
                             self.refs.pop()
                             tf = self.finalise_current_image(result)

@@ -575,3 +575,116 @@ def test_readme_synchronised_flow_through_the_alias_package(cuda, world, tmp_pat
     assert len(shapes) >= 4 and all(abs(a[0] - b[0]) <= 2 and abs(a[1] - b[1]) <= 2 for a, b in shapes)
     assert max(a[1] for a, _ in shapes) > 400
     assert sorted(os.listdir(tmp_path / "rgb")) == sorted(os.listdir(tmp_path / "depth"))
+
+
+def _stream_with_given_tf(cuda, tmp_path, frames, Ms, blender, type_=0, contrib=0.5):
+    """Frames blended onto the resident arena with given transforms (the reference's tf path, stitcher.py:213-214);
+    every mosaic is compared with the oracle pipeline fed the ORACLE's previous mosaic, and the arena invariant
+    (zero outside the mosaic's rectangle) is checked after every frame."""
+    import torch
+    from image_stitcher_amd import ConsecutiveStitcher, TransformDetails
+    st = ConsecutiveStitcher(log_level=3, output_dir=str(tmp_path), type=type_, blender=blender, ref_image_contrib=contrib,
+                             consecutive_range=1, detector=object())
+    cfg = Cfg(type=type_, blender=blender, ref_image_contrib=contrib, consecutive_range=1)
+    st.stitch_consecutive(frames[0])
+    ref, corners = frames[0], None
+    pts = np.zeros((5, 1, 2), np.float32)
+    infos = []
+    for f, M in zip(frames[1:], Ms):
+        tf = TransformDetails(np.asarray(M, np.float64), pts, pts)
+        assert st.stitch_consecutive(f, tf) is tf
+        o = oracle_stitch(ref, f, None, cfg, tf=(tf.M, pts, pts), corners=corners)
+        got = np.asarray(st.refs[-1])
+        assert got.shape == o[0].shape and np.array_equal(got, o[0]), f"{(got != o[0]).sum()} bytes differ"
+        assert st.corners == o[1]
+        ref, corners = o[0], o[1]
+        ar = st.refs[-1]._arena
+        outside = ar.t.clone()
+        outside[ar.y:ar.y + ar.h, ar.x:ar.x + ar.w] = 0
+        assert int(outside.max()) == 0, "arena holds non-zero bytes outside the mosaic"
+        infos.append((ar.t.shape, ar.x, ar.y))
+    return st, infos
+
+
+def _shift(dx, dy):
+    return [[1.0, 0.0, float(dx)], [0.0, 1.0, float(dy)]]
+
+
+def test_resident_arena_grows_and_stays_exact(cuda, orc, world, tmp_path):
+    """12 frames marching right (then down) with sub-pixel rotations: the arena is reallocated only a few times
+    (amortised growth), mosaics stay bit-identical to the oracle's, both blenders."""
+    from image_stitcher_amd.synthetic import crop_path
+    frames = crop_path(world, 12, (200, 260), seed=4, max_rot_deg=0.0)[0]
+    for blender in (1, 0):
+        Ms = []
+        rw = 260
+        for k in range(1, 12):
+            th = np.deg2rad(0.7 * (-1) ** k)
+            c, s = np.cos(th), np.sin(th)
+            # the frame sits at ((rw+260)//2, (rh+200)//2) of the canvas, the mosaic at (260, 200): move the frame
+            # so that it overlaps the mosaic's right end by ~60 %
+            tx, ty = (260 + rw - 160) - (rw + 260) // 2 + 0.3, 5 * (k % 3) - 3.4
+            Ms.append([[c, -s, tx], [s, c, ty]])
+            rw += 100  # approximate; exactness does not depend on it
+        st, infos = _stream_with_given_tf(cuda, tmp_path, frames, Ms, blender)
+        shapes = [i[0] for i in infos]
+        assert len(set(shapes)) <= 5 and st.frame_stats["arena_allocs"] <= 5, f"arena reallocated too often: {shapes}"
+        assert st.frame_stats["frames"] == 11 and st.frame_stats["rescans"] == 0 and st.frame_stats["rows_slow"] == 0
+        assert np.asarray(st.refs[-1]).shape[1] > 260 * 3
+
+
+def test_gradient_rows_outside_roi_take_the_exact_slow_path(cuda, orc, tmp_path):
+    """A frame with a channel-0-only region ((3,0,0): gray == 0, mask > 0 in the reference's per-channel mask,
+    utils/proc.py:207-208) more than 50 px away from its gray content: those pixels lie in the ROI's rows but
+    outside its columns, so the row extents must be taken inside the ROI (result block rows_ok == 0)."""
+    ref = np.full((220, 300, 3), 90, np.uint8)
+    f = np.zeros((200, 300, 3), np.uint8)
+    f[30:170, 20:140] = (120, 80, 200)
+    f[90:110, 250:290] = (3, 0, 0)      # far right of the content, same rows
+    f[5:9, 40:60] = (4, 0, 1)            # gray == 0 but channel 0 != 0, above the content (inside the ROI's columns)
+    st, _ = _stream_with_given_tf(cuda, tmp_path, [ref, f], [_shift(-40, 6)], blender=1)
+    assert st.frame_stats["rows_slow"] == 1
+    f[90:110, 250:290] = 0               # without the far region the fast path is taken, same oracle check
+    st, _ = _stream_with_given_tf(cuda, tmp_path, [ref, f], [_shift(-40, 6)], blender=1)
+    assert st.frame_stats["rows_slow"] == 0 and st.frame_stats["rescans"] == 0
+
+
+def test_alpha_wrap_to_zero_shrinks_the_crop(cuda, orc, tmp_path):
+    """utils/proc.py:79: outside the overlap the alpha blender ADDS with uint8 wrap-around, so 250 + 6 = 0: a pixel
+    of the mosaic that defined its bounding box can turn black, and the crop (stitcher.py:225) then shrinks.  The
+    frame pipeline reports it (result block `zeroed`) and the host rescans; gray == 0 leftovers outside the new crop
+    ((3,0,0) pixels of the frame, `dirty`) are cleared from the arena."""
+    ref = np.zeros((120, 200, 3), np.uint8)
+    ref[10:110, 20:200] = 70
+    ref[60, 0] = (250, 250, 250)         # the only non-black pixel of columns 0..19
+    f = np.zeros((100, 160, 3), np.uint8)
+    f[50, 30] = 6                        # gray 6 <= 10: never "overlap", always added -> lands on ref (0, 60)
+    f[20:80, 60:120] = 6                 # lands on the 70-valued area
+    f[95:97, 60:80] = (3, 0, 0)          # gray == 0 bytes that land below the mosaic's content (ref rows 115..116)
+    # frame pasted at ((200+160)//2, (120+100)//2) = (180, 110); the mosaic at (160, 100): canvas (160, 160) is ref (0, 60)
+    # move frame pixel (30, 50) onto it: 180 + 30 + tx = 160, 110 + 50 + ty = 160
+    M1 = _shift(-50, 0)
+    st, _ = _stream_with_given_tf(cuda, tmp_path, [ref, f], [M1], blender=0, contrib=0.5)
+    assert np.asarray(st.refs[-1]).shape[1] == 180     # columns 0..19 were cropped away
+    assert st.frame_stats["rescans"] == 1 and st.frame_stats["clears"] >= 1
+    # and a second frame lands where the (3,0,0) bytes were: the arena must have been cleared there
+    f2 = np.zeros((100, 160, 3), np.uint8)
+    f2[10:90, 10:150] = 40
+    _stream_with_given_tf(cuda, tmp_path, [ref, f, f2], [M1, _shift(30, -5)], blender=0, contrib=0.5)
+    _stream_with_given_tf(cuda, tmp_path, [ref, f, f2], [M1, _shift(30, -5)], blender=1)
+
+
+def test_public_stitch_does_not_modify_the_reference_mosaic(cuda, world, tmp_path):
+    """Stitcher.stitch called by user code is functional as in the reference: a resident mosaic passed as `ref`
+    keeps its pixels (only ConsecutiveStitcher / stitch_collections, which replace the mosaic by the result, blend
+    in place)."""
+    from image_stitcher_amd import Stitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    frames = _frames(world, 3)
+    st = Stitcher(log_level=3, output_dir=str(tmp_path), algorithm=1, detector=NumpyOrbLite(nfeatures=500))
+    m1, _, _ = st.stitch(frames[0], frames[1])
+    before = np.array(np.asarray(m1))
+    m2, _, _ = st.stitch(m1, frames[2])
+    assert m2.shape[1] > m1.shape[1]
+    m1.invalidate()
+    assert np.array_equal(np.asarray(m1), before)
