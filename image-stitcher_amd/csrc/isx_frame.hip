@@ -1,7 +1,7 @@
 // Per-frame pipeline on a resident mosaic: Stitcher.warp_target + Stitcher.merge + the two bounding boxes of
 // Stitcher.stitch (reference stitcher.py:216-225 -> utils/proc.py:48-82, :192-254, :34-45, :307-312) as ONE
-// entry point that runs 3 (gradient blender) or 2 (alpha blender) dependent launches and returns every
-// per-frame result in one small read-back.
+// entry point that runs 3 (gradient blender) or 1 (alpha blender) launches and returns every per-frame result
+// in one small read-back.
 //
 // The reference builds two padded canvases per call and scans the whole canvas three times.  Here the mosaic
 // lives in a caller-owned arena that is zero outside the mosaic; the frame is warped only over Q, a
@@ -14,42 +14,54 @@
 //                               gray != 0 extent (-> bbox(warped), stitcher.py:220 / proc.py:194) and channel-0
 //                               extent (-> left/right feather edges, proc.py:213-218), a 1-bit/pixel mask of
 //                               channel 0 != 0; plain stores only, nothing to initialise
-//     K2 frame_extent_kernel    every workgroup folds the row table into bbox(warped) and the ROI
-//                               (bbox +- 50 px clipped to the canvas, proc.py:199-201); column extents of the
-//                               horizontally feathered mask (proc.py:230-236) from the bit mask
-//     K3 frame_gradient_kernel  feathered blend in place on the mosaic inside the ROI (proc.py:211-253), bbox
-//                               of the written gray != 0 pixels, zeroed / dirty pixel counts
+//     K2 frame_extent_kernel    one workgroup per 256-column chunk: folds the row table into bbox(warped) and
+//                               the ROI (bbox +- 50 px clipped to the canvas, proc.py:199-201); column extents of
+//                               the horizontally feathered mask (proc.py:230-236) by a ballot transpose of the
+//                               bit mask -- one wave owns 64 columns, so no atomics and nothing to initialise
+//     K3 frame_gradient_kernel  feathered blend in place on the mosaic inside the ROI (proc.py:211-253); per-
+//                               workgroup partials of the written pixels' bbox and the zeroed / dirty flags
 //   alpha blender (utils/proc.py:48-82)
-//     K1 frame_warp_alpha_kernel  warp + blend in place, per-row tables of both bounding boxes and counts
-//     K2 frame_alpha_finish_kernel  folds the tables
+//     K1 frame_warp_alpha_kernel  warp + blend in place, per-row table of both bounding boxes and the flags
+//   The small tables (K3's partials / the alpha row table) come back with the result block in ONE device-to-
+//   host copy and are folded on the host: a fold kernel would cost a dependent launch (4-8 us measured) for a
+//   few microseconds of PCIe.  No same-address atomics anywhere: device-scope atomics from different XCDs are
+//   resolved at the memory side, ~30 ns each, serialised per address (the first version spent 16 + 50 us there).
 #include "isx_common.h"
 #include "isx_image_dev.h"
 #include <string.h>
 
-// result block (int32), device and pinned host copies
+// result block (int32)
 enum {
-    R_WBBOX = 0,   // 5: bbox of gray != 0 warped pixels, canvas coordinates {x0,y0,x1,y1,found}
-    R_ROI = 5,     // 4: gradient ROI {gx0,gy0,gx1,gy1} (canvas coordinates)
-    R_MBBOX = 9,   // 5: bbox of gray != 0 pixels among the pixels written into the mosaic
-    R_ZEROED = 14, // pixels whose gray was != 0 before the blend and is 0 after it
-    R_DIRTY = 15,  // pixels written with gray == 0 but a byte != 0 (must not survive outside the crop)
+    R_WBBOX = 0,    // 5: bbox of gray != 0 warped pixels, canvas coordinates {x0,y0,x1,y1,found}
+    R_ROI = 5,      // 4: gradient ROI {gx0,gy0,gx1,gy1} (canvas coordinates)
+    R_MBBOX = 9,    // 5: bbox of gray != 0 pixels among the pixels written into the mosaic
+    R_ZEROED = 14,  // != 0: some pixel's gray was != 0 before the blend and is 0 after it
+    R_DIRTY = 15,   // != 0: some pixel was written with gray == 0 but a byte != 0
     R_ROWS_OK = 16, // gradient: every channel-0 != 0 pixel of the ROI's rows lies inside the ROI's columns
-    R_DONE = 17,   // the blend kernel ran (0: nothing warped, or rows_ok == 0 -> the caller takes the slow path)
+    R_DONE = 17,    // the blend ran (0: nothing warped, or rows_ok == 0 -> the caller takes the slow path)
     R_INTS = ISX_FRAME_RESULT_INTS
 };
+#define FRAME_MAX_WAVES 16
+#define FE_BATCH 1536 // rows of bit mask staged in LDS at a time (48 KiB)
 
 struct isx_ctx {
     int device;
     uint8_t *wbuf;
     size_t wbuf_cap;
-    int32_t *rows; // gradient: 4 x qh {GL, GR, L0, R0}; alpha: 8 x qh
+    int32_t *rows; // gradient: qh x int4 {GL, GR, L0, R0} (gray != 0 extent, channel-0 != 0 extent; canvas x)
     size_t rows_cap;
     int32_t *cols; // 2 x qw {top, bottom}
     size_t cols_cap;
     uint64_t *mask; // qh x nchunk x 4 ballots
     size_t mask_cap;
-    int32_t *res_dev;
-    int32_t *res_host; // pinned
+    int32_t *out_dev; // R_INTS result ints, then the table folded on the host
+    size_t out_cap;
+    int32_t *out_host; // pinned mirror of out_dev
+    size_t out_host_cap;
+    int pending;    // kernels queued whose results have not been read back: 1 = gradient, 2 = alpha
+    int fold_n;     // entries of the table behind the result block (gradient: workgroups of K3; alpha: rows of Q)
+    int fold_qy0;   // alpha: canvas y of the table's first row
+    int32_t last[R_INTS];
 };
 
 template <typename T>
@@ -64,16 +76,32 @@ static int ctx_ensure(T **p, size_t *cap, size_t need) {
     return ISX_OK;
 }
 
+static int ctx_ensure_out(isx_ctx *c, size_t ints) {
+    int rc = ctx_ensure(&c->out_dev, &c->out_cap, ints);
+    if (rc != ISX_OK) return rc;
+    if (c->out_host_cap < c->out_cap) {
+        if (c->out_host) ISX_HIP_TRY(hipHostFree(c->out_host));
+        c->out_host = nullptr;
+        c->out_host_cap = 0;
+        ISX_HIP_TRY(hipHostMalloc((void **)&c->out_host, c->out_cap * 4, hipHostMallocDefault));
+        c->out_host_cap = c->out_cap;
+    }
+    return ISX_OK;
+}
+
 extern "C" int isx_ctx_create(isx_ctx **out) {
     ISX_REQUIRE(out, "null out");
     isx_ctx *c = new isx_ctx();
     memset(c, 0, sizeof(*c));
-    if (hipGetDevice(&c->device) != hipSuccess || hipMalloc((void **)&c->res_dev, R_INTS * 4) != hipSuccess ||
-        hipHostMalloc((void **)&c->res_host, R_INTS * 4, hipHostMallocDefault) != hipSuccess) {
+    if (hipGetDevice(&c->device) != hipSuccess) {
         const hipError_t e = hipGetLastError();
-        if (c->res_dev) (void)hipFree(c->res_dev);
         delete c;
         return isx_fail(ISX_E_HIP, "isx_ctx_create: %s", hipGetErrorString(e));
+    }
+    const int rc = ctx_ensure_out(c, 4096);
+    if (rc != ISX_OK) {
+        delete c;
+        return rc;
     }
     *out = c;
     return ISX_OK;
@@ -85,241 +113,520 @@ extern "C" int isx_ctx_destroy(isx_ctx *c) {
     if (c->rows) (void)hipFree(c->rows);
     if (c->cols) (void)hipFree(c->cols);
     if (c->mask) (void)hipFree(c->mask);
-    if (c->res_dev) (void)hipFree(c->res_dev);
-    if (c->res_host) (void)hipHostFree(c->res_host);
+    if (c->out_dev) (void)hipFree(c->out_dev);
+    if (c->out_host) (void)hipHostFree(c->out_host);
     delete c;
     return ISX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1 (gradient path).  grid = qh workgroups of 256; wave w takes the 256-pixel chunks w, w+4, ... of its row.
+// Four horizontally adjacent warped pixels (float32 arithmetic, affine or perspective).  When EVERY pixel of the
+// wave takes warp_pixel's wide-load path (both taps of both rows inside the frame) the per-tap validity logic,
+// the guard and the slow path are skipped wave-uniformly: the same loads and the same FMAs, about a third of
+// the vector instructions -- this kernel is VALU-bound (150 instructions per pixel in the general form).
 // ------------------------------------------------------------------------------------------------
-template <int C, bool PERSP, bool CLASSIC>
-__global__ void __launch_bounds__(256) frame_warp_kernel(const uint8_t *__restrict__ src, const WarpParams P,
-                                                         uint8_t *__restrict__ wbuf, int nchunk,
-                                                         int32_t *__restrict__ rows, uint64_t *__restrict__ mask,
-                                                         int32_t *__restrict__ cols) {
-    const int ly = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int gl = INT_MAX, gr = -1, l0 = INT_MAX, r0 = -1;
-    for (int chunk = wave; chunk < nchunk; chunk += 4) {
-        const int lx = chunk * 256 + 4 * lane;
-        uint32_t px[4];
+// one tap of the general path: pixel (cx, cy) of the frame, coordinates already clamped into the frame; the
+// 4-byte load is pulled back by one byte at the end of a row so that it never leaves the row (needs sw*C >= 4)
+template <int C>
+__device__ __forceinline__ uint32_t tap_clamped(const uint8_t *__restrict__ src, const WarpParams &P, int cx, int cy) {
+    if (C == 3) {
+        const int want = cx * 3, off = min(want, P.sw * 3 - 4);
+        const uint32_t v = *(const u32u *)(src + ((uint32_t)cy * (uint32_t)P.spitch + (uint32_t)off));
+        return (v >> (8 * (want - off))) & 0xFFFFFFu;
+    }
+    return src[(uint32_t)cy * (uint32_t)P.spitch + (uint32_t)cx];
+}
+
+template <int C, bool PERSP>
+__device__ __forceinline__ void warp_quad_f32(const uint8_t *__restrict__ src, const WarpParams &P, int X0, int Y, int n_valid,
+                                              uint32_t (&px)[4]) {
+    const float fy = (float)Y;
+    const float tx = fmaf(P.m[1], fy, P.m[2]), ty = fmaf(P.m[4], fy, P.m[5]), tw = fmaf(P.m[7], fy, P.m[8]);
+    const float x_lo = (float)P.src_x, x_hi = (float)(P.src_x + P.sw), y_lo = (float)P.src_y, y_hi = (float)(P.src_y + P.sh);
+    // "inside": both taps of both rows in the frame and the wide load inside the row (warp_pixel's `wide`):
+    //   0 <= floor(sx) - src_x <= sw - 3 (C = 3; sw - 2 for C = 1)  and  0 <= floor(sy) - src_y <= sh - 2
+    const float x_in = x_hi - (C == 3 ? 2.f : 1.f), y_in = y_hi - 1.f;
+    float sx[4], sy[4];
+    bool inside, outside;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-            px[i] = lx + i >= P.dw ? 0u
-                    : CLASSIC  ? warp_pixel_classic<C, PERSP>(src, P, P.dx0 + lx + i, P.dy0 + ly)
-                               : warp_pixel<C, PERSP>(src, P, P.dx0 + lx + i, P.dy0 + ly);
-        if (lx < P.dw) quad_store<C>(wbuf + (int64_t)ly * P.dpitch, lx, P.dw, px);
-        uint64_t b[4];
+    for (int i = 0; i < 4; i++) {
+        const float fx = (float)(X0 + i);
+        sx[i] = fmaf(P.m[0], fx, tx);
+        sy[i] = fmaf(P.m[3], fx, ty);
+        if (PERSP) {
+            const float w = fmaf(P.m[6], fx, tw);
+            sx[i] = sx[i] / w;
+            sy[i] = sy[i] / w;
+        }
+    }
+    if (!PERSP) {
+        // affine: fmaf(m, fx, t) is monotone in fx, so the four pixels of the lane lie between its end pixels and
+        // two of them decide for all four
+        inside = n_valid == 4 && sx[0] >= x_lo && sx[0] < x_in && sx[3] >= x_lo && sx[3] < x_in && sy[0] >= y_lo && sy[0] < y_in &&
+                 sy[3] >= y_lo && sy[3] < y_in;
+        outside = (sx[0] <= x_lo - 2.f && sx[3] <= x_lo - 2.f) || (sx[0] >= x_hi + 1.f && sx[3] >= x_hi + 1.f) ||
+                  (sy[0] <= y_lo - 2.f && sy[3] <= y_lo - 2.f) || (sy[0] >= y_hi + 1.f && sy[3] >= y_hi + 1.f) || n_valid == 0;
+    } else {
+        inside = n_valid == 4;
+        outside = true;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int X = P.dx0 + lx + i;
-            if (gray_px<C>(px[i]) != 0) {
-                gl = min(gl, X);
-                gr = max(gr, X);
+            inside = inside && sx[i] >= x_lo && sx[i] < x_in && sy[i] >= y_lo && sy[i] < y_in;
+            outside = outside && !(i < n_valid && sx[i] > x_lo - 2.f && sx[i] < x_hi + 1.f && sy[i] > y_lo - 2.f && sy[i] < y_hi + 1.f);
+        }
+    }
+    if (__all(outside)) { // margins of Q: nothing to fetch
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] = 0u;
+        return;
+    }
+#ifdef ISX_DIAG_K1_NOGENERAL // A/B only: border waves produce zeros (WRONG results) to see what the general path costs
+    if (!__all(inside)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] = 0u;
+        return;
+    }
+#endif
+    if (__all(inside)) {
+        const uint32_t sp = (uint32_t)P.spitch; // the frame is smaller than 2 GiB (checked by the host): 32-bit offsets
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float flx = floorf(sx[i]), fly = floorf(sy[i]);
+            const float a = sx[i] - flx, b = sy[i] - fly;
+            const uint32_t off = (uint32_t)((int)fly - P.src_y) * sp + (uint32_t)((int)flx - P.src_x) * C;
+            const uint8_t *r0 = src + off;
+            uint32_t o = 0;
+            if (C == 3) {
+                const uint64_t q0 = *(const u64u *)r0, q1 = *(const u64u *)(r0 + sp);
+                const uint32_t q0l = (uint32_t)q0, q0h = (uint32_t)(q0 >> 32), q1l = (uint32_t)q1, q1h = (uint32_t)(q1 >> 32);
+                // taps: bytes 0..2 = left pixel, bytes 3..5 = right pixel
+                const float f00[3] = {(float)(q0l & 255u), (float)((q0l >> 8) & 255u), (float)((q0l >> 16) & 255u)};
+                const float f01[3] = {(float)(q0l >> 24), (float)(q0h & 255u), (float)((q0h >> 8) & 255u)};
+                const float f10[3] = {(float)(q1l & 255u), (float)((q1l >> 8) & 255u), (float)((q1l >> 16) & 255u)};
+                const float f11[3] = {(float)(q1l >> 24), (float)(q1h & 255u), (float)((q1h >> 8) & 255u)};
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float t0 = fmaf(a, f01[c] - f00[c], f00[c]), t1 = fmaf(a, f11[c] - f10[c], f10[c]);
+                    // a convex combination of bytes, rounded once per FMA: always inside [0, 255]; rintf first, so the
+                    // conversion inside the pack instruction has nothing left to round
+                    o = __builtin_amdgcn_cvt_pk_u8_f32(rintf(fmaf(b, t1 - t0, t0)), c, o);
+                }
+            } else {
+                const uint32_t q0 = *(const u16u *)r0, q1 = *(const u16u *)(r0 + sp);
+                const float f00 = (float)(q0 & 255u), f01 = (float)(q0 >> 8), f10 = (float)(q1 & 255u), f11 = (float)(q1 >> 8);
+                const float t0 = fmaf(a, f01 - f00, f00), t1 = fmaf(a, f11 - f10, f10);
+                o = (uint32_t)(int)rintf(fmaf(b, t1 - t0, t0));
             }
-            const bool c0 = (px[i] & 255u) != 0u;
-            if (c0) {
-                l0 = min(l0, X);
-                r0 = max(r0, X);
+            px[i] = o;
+        }
+        return;
+    }
+    bool guard[4];
+    float flx[4], fly[4];
+    int ix[4], iy[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        // warp_pixel's guard (a NaN fails it); (int)floorf() is only formed from values inside it
+        guard[i] = i < n_valid && sx[i] > x_lo - 2.f && sx[i] < x_hi + 1.f && sy[i] > y_lo - 2.f && sy[i] < y_hi + 1.f;
+        flx[i] = floorf(guard[i] ? sx[i] : x_lo);
+        fly[i] = floorf(guard[i] ? sy[i] : y_lo);
+        ix[i] = (int)flx[i] - P.src_x;
+        iy[i] = (int)fly[i] - P.src_y;
+    }
+    // the frame's border: taps outside the frame are the constant-0 border.  BRANCH-FREE: every tap is fetched from
+    // clamped coordinates and masked afterwards, so the 16 loads of a lane are in flight together (the per-tap
+    // branches of warp_pixel serialise up to 12 memory round trips per pixel, and one such wave sets the kernel time)
+    uint32_t t00[4], t01[4], t10[4], t11[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int cx0 = min(max(ix[i], 0), P.sw - 1), cx1 = min(max(ix[i] + 1, 0), P.sw - 1);
+        const int cy0 = min(max(iy[i], 0), P.sh - 1), cy1 = min(max(iy[i] + 1, 0), P.sh - 1);
+        t00[i] = tap_clamped<C>(src, P, cx0, cy0);
+        t01[i] = tap_clamped<C>(src, P, cx1, cy0);
+        t10[i] = tap_clamped<C>(src, P, cx0, cy1);
+        t11[i] = tap_clamped<C>(src, P, cx1, cy1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const bool x0ok = (unsigned)ix[i] < (unsigned)P.sw, x1ok = (unsigned)(ix[i] + 1) < (unsigned)P.sw;
+        const bool y0ok = (unsigned)iy[i] < (unsigned)P.sh, y1ok = (unsigned)(iy[i] + 1) < (unsigned)P.sh;
+        const uint32_t p00 = (guard[i] && x0ok && y0ok) ? t00[i] : 0u, p01 = (guard[i] && x1ok && y0ok) ? t01[i] : 0u;
+        const uint32_t p10 = (guard[i] && x0ok && y1ok) ? t10[i] : 0u, p11 = (guard[i] && x1ok && y1ok) ? t11[i] : 0u;
+        const float a = sx[i] - flx[i], b = sy[i] - fly[i];
+        uint32_t o = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float f00 = (float)((p00 >> (8 * c)) & 255u), f01 = (float)((p01 >> (8 * c)) & 255u);
+            const float f10 = (float)((p10 >> (8 * c)) & 255u), f11 = (float)((p11 >> (8 * c)) & 255u);
+            const float t0 = fmaf(a, f01 - f00, f00), t1 = fmaf(a, f11 - f10, f10);
+            o |= (uint32_t)(int)rintf(fmaf(b, t1 - t0, t0)) << (8 * c);
+        }
+        px[i] = guard[i] ? o : 0u;
+    }
+}
+
+template <int C, bool PERSP, bool CLASSIC>
+__device__ __forceinline__ void warp_quad(const uint8_t *__restrict__ src, const WarpParams &P, int X0, int Y, int n_valid,
+                                          uint32_t (&px)[4]) {
+    if (CLASSIC) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) px[i] = i < n_valid ? warp_pixel_classic<C, PERSP>(src, P, X0 + i, Y) : 0u;
+    } else {
+        warp_quad_f32<C, PERSP>(src, P, X0, Y, n_valid, px);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 (gradient path).  grid = qh workgroups of nw = min(nchunk, 16) waves; wave w takes the 256-pixel chunks
+// w, w+nw, ... of its row (one chunk per wave up to 4096-pixel rows).
+// ------------------------------------------------------------------------------------------------
+template <int C, bool PERSP, bool CLASSIC>
+__global__ void __launch_bounds__(1024) frame_warp_kernel(const uint8_t *__restrict__ src, const WarpParams P,
+                                                          uint8_t *__restrict__ wbuf, int nchunk,
+                                                          int32_t *__restrict__ rows, uint64_t *__restrict__ mask) {
+    const int ly = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int gl = INT_MAX, gr = -1, l0 = INT_MAX, r0 = -1;
+    for (int chunk = wave; chunk < nchunk; chunk += nw) {
+        const int lx = chunk * 256 + 4 * lane;
+        const int nv = min(4, max(0, P.dw - lx));
+        uint32_t px[4];
+        warp_quad<C, PERSP, CLASSIC>(src, P, P.dx0 + lx, P.dy0 + ly, nv, px);
+        if (nv > 0) quad_store<C>(wbuf + (int64_t)ly * P.dpitch, lx, P.dw, px);
+        // extents from ballots: bit l of word i is pixel 4*l + i of the chunk; the scalar unit finds the first / last
+        // set bit, no per-lane min/max and no cross-lane reduction
+        uint64_t bc[4], bg[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            bc[i] = __ballot((px[i] & 255u) != 0u);
+            bg[i] = C == 3 ? __ballot(gray_px<C>(px[i]) != 0) : bc[i];
+        }
+        const int cx = P.dx0 + chunk * 256;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (bg[i]) {
+                gl = min(gl, cx + 4 * (int)__builtin_ctzll(bg[i]) + i);
+                gr = max(gr, cx + 4 * (63 - (int)__builtin_clzll(bg[i])) + i);
             }
-            b[i] = __ballot(c0);
+            if (bc[i]) {
+                l0 = min(l0, cx + 4 * (int)__builtin_ctzll(bc[i]) + i);
+                r0 = max(r0, cx + 4 * (63 - (int)__builtin_clzll(bc[i])) + i);
+            }
         }
         if (lane == 0) {
             uint64_t *m = mask + ((int64_t)ly * nchunk + chunk) * 4;
-            m[0] = b[0], m[1] = b[1], m[2] = b[2], m[3] = b[3];
+            m[0] = bc[0], m[1] = bc[1], m[2] = bc[2], m[3] = bc[3];
         }
     }
-    __shared__ int red[4][4];
-    gl = wave_min(gl), gr = wave_max(gr), l0 = wave_min(l0), r0 = wave_max(r0);
-    if (lane == 0) red[wave][0] = gl, red[wave][1] = gr, red[wave][2] = l0, red[wave][3] = r0;
+    __shared__ int red[FRAME_MAX_WAVES][4];
+    if (lane == 0) red[wave][0] = gl, red[wave][1] = gr, red[wave][2] = l0, red[wave][3] = r0; // (wave-uniform values)
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) {
+        for (int w = 1; w < nw; w++) {
             gl = min(gl, red[w][0]);
             gr = max(gr, red[w][1]);
             l0 = min(l0, red[w][2]);
             r0 = max(r0, red[w][3]);
         }
-        rows[ly] = gl;
-        rows[P.dh + ly] = gr;
-        rows[2 * P.dh + ly] = l0;
-        rows[3 * P.dh + ly] = r0;
-    }
-    // column-extent accumulators of K2 (this kernel precedes it on the stream)
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < P.dw; i += gridDim.x * 256) {
-        cols[i] = INT_MAX;
-        cols[P.dw + i] = -1;
+        ((int4 *)rows)[ly] = make_int4(gl, gr, l0, r0);
     }
 }
 
-// block-wide min/max of four values; every thread of the 256-thread block calls it and gets the result
+// block-wide min/max of four values; every thread of the block (up to FRAME_MAX_WAVES waves) calls it and gets
+// the result
 __device__ __forceinline__ void block_minmax4(int &a, int &b, int &c, int &d, int (*red)[4]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     a = wave_min(a), b = wave_min(b), c = wave_max(c), d = wave_max(d);
     __syncthreads(); // red may still be read from a previous call
     if (lane == 0) red[wave][0] = a, red[wave][1] = b, red[wave][2] = c, red[wave][3] = d;
     __syncthreads();
-    a = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
-    b = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
-    c = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
-    d = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+    a = red[0][0], b = red[0][1], c = red[0][2], d = red[0][3];
+    for (int w = 1; w < nw; w++) {
+        a = min(a, red[w][0]);
+        b = min(b, red[w][1]);
+        c = max(c, red[w][2]);
+        d = max(d, red[w][3]);
+    }
+}
+
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        lo |= (uint32_t)__shfl_xor((int)lo, m);
+        hi |= (uint32_t)__shfl_xor((int)hi, m);
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2 (gradient path).  grid = (nchunk, ceil(qh / 64)).  Every workgroup folds the row table (a few KB from
-// L2) so that no grid-wide synchronisation is needed; workgroup (0,0) publishes the result block.
+// K2 (gradient path).  grid = nchunk workgroups of 1024.  Every workgroup folds the row table (a few KB from L2),
+// so no grid-wide synchronisation is needed; workgroup 0 publishes the result block.  Wave k < 4 of workgroup c
+// then owns the 64 columns 256c + 4i + k (bit i of ballot word k, the layout K1 stores): rows sit on the lanes,
+// and for every column that shows its first (last) set bit in a 64-row group one ballot turns that bit column
+// into a 64-bit row mask whose lowest (highest) set bit is the row.  Each column is visited once per direction.
+// All global loads (row table + this chunk's bit mask) are issued up front, in one round trip: at this size
+// a kernel costs its dependent memory round trips, not its bytes.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) frame_extent_kernel(const int32_t *__restrict__ rows, int qx0, int qy0, int qw,
-                                                           int qh, int canvas_w, int canvas_h, int margin,
-                                                           const uint64_t *__restrict__ mask, int nchunk,
-                                                           int32_t *__restrict__ cols, int32_t *__restrict__ res) {
-    __shared__ int red[4][4];
-    __shared__ uint64_t wm[64][4];
-    __shared__ int sl[64], sr[64];
-    int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1;
-    for (int ly = threadIdx.x; ly < qh; ly += 256) {
-        const int gr = rows[qh + ly];
-        if (gr >= 0) {
-            x0 = min(x0, rows[ly]);
-            x1 = max(x1, gr + 1);
+#define FE_ROWS_PER_THREAD ((FE_BATCH + 1023) / 1024)
+#define FE_WORDS_PER_THREAD ((FE_BATCH * 4 + 1023) / 1024)
+__global__ void __launch_bounds__(1024) frame_extent_kernel(const int32_t *__restrict__ rows, int qx0, int qy0, int qw,
+                                                            int qh, int canvas_w, int canvas_h, int margin,
+                                                            const uint64_t *__restrict__ mask, int nchunk,
+                                                            int32_t *__restrict__ cols, int32_t *__restrict__ res) {
+    __shared__ uint64_t wm[FE_BATCH][4];
+    __shared__ uint64_t or8[FE_BATCH / 8][4];
+    __shared__ uint64_t gor[FE_BATCH / 64][4];
+    const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+    const int chunk = blockIdx.x, cx0 = qx0 + chunk * 256; // canvas x of the chunk's first column
+    const int4 *rt = (const int4 *)rows;
+    // ---- fold the row table: bbox of gray != 0 pixels; any channel-0 extent outside [lo, hi) is checked later ----
+    int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1, l0min = INT_MAX, r0max = -1;
+    uint64_t wv[FE_WORDS_PER_THREAD];
+    int4 wr[FE_WORDS_PER_THREAD];
+    const int n0 = min(FE_BATCH, qh); // first batch: rows [0, n0) of Q
+#pragma unroll
+    for (int u = 0; u < FE_WORDS_PER_THREAD; u++) {
+        const int t = threadIdx.x + 1024 * u, r = min(t >> 2, n0 - 1);
+        wv[u] = mask[((int64_t)r * nchunk + chunk) * 4 + (t & 3)];
+        wr[u] = rt[r];
+    }
+    for (int ly = threadIdx.x; ly < qh; ly += 1024) {
+        const int4 e = rt[ly];
+        if (e.y >= 0) {
+            x0 = min(x0, e.x);
+            x1 = max(x1, e.y + 1);
             y0 = min(y0, qy0 + ly);
             y1 = max(y1, qy0 + ly + 1);
         }
+        if (e.w >= 0) { // channel-0 extent over ALL rows of Q (a superset of the ROI's rows: conservative)
+            l0min = min(l0min, e.z);
+            r0max = max(r0max, e.w);
+        }
     }
-    block_minmax4(x0, y0, x1, y1, red);
+    {   // one block-wide fold of the six values
+        __shared__ int red6[FRAME_MAX_WAVES][6];
+        x0 = wave_min(x0), y0 = wave_min(y0), l0min = wave_min(l0min);
+        x1 = wave_max(x1), y1 = wave_max(y1), r0max = wave_max(r0max);
+        if (lane == 0) red6[k][0] = x0, red6[k][1] = y0, red6[k][2] = l0min, red6[k][3] = x1, red6[k][4] = y1, red6[k][5] = r0max;
+        __syncthreads();
+        for (int w = 0; w < FRAME_MAX_WAVES; w++) {
+            x0 = min(x0, red6[w][0]), y0 = min(y0, red6[w][1]), l0min = min(l0min, red6[w][2]);
+            x1 = max(x1, red6[w][3]), y1 = max(y1, red6[w][4]), r0max = max(r0max, red6[w][5]);
+        }
+    }
     const bool found = x1 >= 0;
-    const bool first = blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
     if (!found) {
         if (first) {
             res[R_WBBOX + 0] = res[R_WBBOX + 1] = INT_MAX;
             res[R_WBBOX + 2] = res[R_WBBOX + 3] = -1;
             res[R_WBBOX + 4] = 0;
             res[R_ROI + 0] = res[R_ROI + 1] = res[R_ROI + 2] = res[R_ROI + 3] = 0;
-            res[R_MBBOX + 0] = res[R_MBBOX + 1] = INT_MAX;
-            res[R_MBBOX + 2] = res[R_MBBOX + 3] = -1;
-            res[R_MBBOX + 4] = 0;
-            res[R_ZEROED] = res[R_DIRTY] = 0;
             res[R_ROWS_OK] = 1;
-            res[R_DONE] = 0;
         }
         return;
     }
     const int gx0 = max(0, x0 - margin), gy0 = max(0, y0 - margin);
     const int gx1 = min(canvas_w, x1 + margin), gy1 = min(canvas_h, y1 + margin);
-    // rows_ok: no channel-0 pixel of an ROI row outside the ROI's columns (then the row extents K1 took
-    // over all of Q are the ROI's own, proc.py:213-218)
-    int bad = 0, d1 = 0, d2 = 0, d3 = 0;
-    for (int ly = max(0, gy0 - qy0) + threadIdx.x; ly < min(qh, gy1 - qy0); ly += 256) {
-        const int r0 = rows[3 * qh + ly];
-        if (r0 >= 0 && (rows[2 * qh + ly] < gx0 || r0 >= gx1)) bad = 1;
-    }
-    block_minmax4(d1, d2, bad, d3, red);
+    const int ly_lo = max(0, gy0 - qy0), ly_hi = min(qh, gy1 - qy0);
+    // rows_ok: no channel-0 pixel outside the ROI's columns (then the row extents K1 took over all of Q are the
+    // ROI's own, proc.py:213-218).  Tested over all rows of Q, which can only send more frames to the exact slow path.
+    const bool bad = r0max >= 0 && (l0min < gx0 || r0max >= gx1);
     if (first) {
         res[R_WBBOX + 0] = x0, res[R_WBBOX + 1] = y0, res[R_WBBOX + 2] = x1, res[R_WBBOX + 3] = y1, res[R_WBBOX + 4] = 1;
         res[R_ROI + 0] = gx0, res[R_ROI + 1] = gy0, res[R_ROI + 2] = gx1, res[R_ROI + 3] = gy1;
-        res[R_MBBOX + 0] = res[R_MBBOX + 1] = INT_MAX;
-        res[R_MBBOX + 2] = res[R_MBBOX + 3] = -1;
-        res[R_MBBOX + 4] = 0;
-        res[R_ZEROED] = res[R_DIRTY] = 0;
         res[R_ROWS_OK] = !bad;
-        res[R_DONE] = 0;
     }
     if (bad) return;
-    // column extents over this workgroup's 64 rows x 256 columns
-    const int chunk = blockIdx.x, lyb = blockIdx.y * 64;
-    {
-        const int r = threadIdx.x >> 2, k = threadIdx.x & 3, ly = lyb + r;
-        const bool in = ly < qh && qy0 + ly >= gy0 && qy0 + ly < gy1;
-        wm[r][k] = in ? mask[((int64_t)ly * nchunk + chunk) * 4 + k] : 0ull;
-        if (threadIdx.x < 64) {
-            const int l2 = lyb + threadIdx.x;
-            const bool in2 = l2 < qh;
-            sl[threadIdx.x] = in2 ? rows[2 * qh + l2] : INT_MAX;
-            sr[threadIdx.x] = in2 ? rows[3 * qh + l2] : -1;
+    // ---- column extents.  Per batch of rows: stage the (edge-cleared, ROI-clipped) bit words in LDS, OR them per
+    // 8 rows and per 64 rows, then ONE THREAD PER COLUMN walks group words -> 8-row words -> rows: three short
+    // levels whose LDS reads are issued together (registers), no cross-lane traffic, no atomics, one writer per column.
+    const int n_batch = (qh + FE_BATCH - 1) / FE_BATCH;
+    int mytop = INT_MAX, mybot = -1;
+    const int ck = (threadIdx.x >> 6) & 3, ci = lane; // column thread (waves 0..3): word ck, bit ci -> column 4*ci + ck
+    for (int bi = 0; bi < n_batch; bi++) {
+        const int base = bi * FE_BATCH, n = min(FE_BATCH, qh - base);
+        __syncthreads();
+        if (bi > 0) { // (the first batch was fetched at the top of the kernel)
+#pragma unroll
+            for (int u = 0; u < FE_WORDS_PER_THREAD; u++) {
+                const int t = threadIdx.x + 1024 * u, r = min(t >> 2, n - 1);
+                wv[u] = mask[((int64_t)(base + r) * nchunk + chunk) * 4 + (t & 3)];
+                wr[u] = rt[base + r];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FE_WORDS_PER_THREAD; u++) { // all FE_BATCH rows are written (zeros beyond n)
+            const int t = threadIdx.x + 1024 * u, r = t >> 2, kk = t & 3;
+            uint64_t w = r < n ? wv[u] : 0ull;
+            // the horizontally feathered mask is 0 at both edges of its row (alpha = 0/f): clear those bits;
+            // rows outside the ROI do not take part
+            const int eL = wr[u].z - cx0, eR = wr[u].w - cx0;
+            if (eL >= 0 && eL < 256 && (eL & 3) == kk) w &= ~(1ull << (eL >> 2));
+            if (eR >= 0 && eR < 256 && (eR & 3) == kk) w &= ~(1ull << (eR >> 2));
+            if (base + r < ly_lo || base + r >= ly_hi) w = 0ull;
+            if (r < FE_BATCH) wm[r][kk] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < (FE_BATCH / 8) * 4) { // OR of every 8 rows
+            const int s8 = threadIdx.x >> 2, kk = threadIdx.x & 3;
+            uint64_t o = 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) o |= wm[s8 * 8 + r][kk];
+            or8[s8][kk] = o;
+        }
+        __syncthreads();
+        if (threadIdx.x < (FE_BATCH / 64) * 4) { // OR of every 64 rows
+            const int g = threadIdx.x >> 2, kk = threadIdx.x & 3;
+            uint64_t o = 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++) o |= or8[g * 8 + r][kk];
+            gor[g][kk] = o;
+        }
+        __syncthreads();
+        if (k < 4) {
+            int tg = -1, bg = -1;
+            {
+                bool h[FE_BATCH / 64];
+#pragma unroll
+                for (int g = 0; g < FE_BATCH / 64; g++) h[g] = (gor[g][ck] >> ci) & 1ull;
+#pragma unroll
+                for (int g = FE_BATCH / 64 - 1; g >= 0; g--) tg = h[g] ? g : tg;
+#pragma unroll
+                for (int g = 0; g < FE_BATCH / 64; g++) bg = h[g] ? g : bg;
+            }
+            if (bg >= 0) {
+                bool ht[8], hb[8];
+                int ts = 0, bs = 0, tr = 0, br = 0;
+#pragma unroll
+                for (int r = 0; r < 8; r++) ht[r] = (or8[tg * 8 + r][ck] >> ci) & 1ull, hb[r] = (or8[bg * 8 + r][ck] >> ci) & 1ull;
+#pragma unroll
+                for (int r = 7; r >= 0; r--) ts = ht[r] ? r : ts;
+#pragma unroll
+                for (int r = 0; r < 8; r++) bs = hb[r] ? r : bs;
+                const int trow = (tg * 8 + ts) * 8, brow = (bg * 8 + bs) * 8;
+#pragma unroll
+                for (int r = 0; r < 8; r++) ht[r] = (wm[trow + r][ck] >> ci) & 1ull, hb[r] = (wm[brow + r][ck] >> ci) & 1ull;
+#pragma unroll
+                for (int r = 7; r >= 0; r--) tr = ht[r] ? r : tr;
+#pragma unroll
+                for (int r = 0; r < 8; r++) br = hb[r] ? r : br;
+                if (mytop == INT_MAX) mytop = qy0 + base + trow + tr;
+                mybot = qy0 + base + brow + br;
+            }
         }
     }
-    __syncthreads();
-    const int lx = chunk * 256 + threadIdx.x, X = qx0 + lx;
-    if (lx >= qw || X < gx0 || X >= gx1) return;
-    const int i = threadIdx.x >> 2, k = threadIdx.x & 3;
-    int top = INT_MAX, bot = -1;
-    for (int r = 0; r < 64; r++) {
-        // the horizontally feathered mask is > 0 where channel 0 is != 0 and x is neither edge of its row
-        if (((wm[r][k] >> i) & 1ull) && X != sl[r] && X != sr[r]) {
-            top = min(top, qy0 + lyb + r);
-            bot = qy0 + lyb + r;
-        }
-    }
-    if (bot >= 0) {
-        atomicMin(&cols[lx], top);
-        atomicMax(&cols[qw + lx], bot);
+    const int lx = chunk * 256 + 4 * ci + ck;
+    if (k < 4 && lx < qw) {
+        cols[lx] = mytop;
+        cols[qw + lx] = mybot;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // K3 (gradient path).  Tile = 256 pixels x 8 rows of Q; only pixels inside the ROI are blended.
-// mosaic_q = the arena pixel under canvas (qx0, qy0).
+// mosaic_q = the arena pixel under canvas (qx0, qy0).  A pixel outside every feather band has mask 1 (warped
+// channel > 0) or 0, for which  warped*mask + ref*(1-mask)  is exactly the warped or the reference byte: waves
+// without a feathered pixel skip the float64 arithmetic altogether.
 // ------------------------------------------------------------------------------------------------
 template <int C>
 __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__restrict__ wbuf, int64_t wpitch,
                                                              uint8_t *mosaic_q, int64_t mpitch, int qx0, int qy0,
                                                              int qw, int qh, const int32_t *__restrict__ rows,
-                                                             const int32_t *__restrict__ cols, int feather, int ox0,
-                                                             int oy0, int ox1, int oy1, int32_t *__restrict__ res) {
-    if (!res[R_WBBOX + 4] || !res[R_ROWS_OK]) return;
-    const int gx0 = res[R_ROI + 0], gy0 = res[R_ROI + 1], gx1 = res[R_ROI + 2], gy1 = res[R_ROI + 3];
+                                                             const int32_t *__restrict__ cols, int feather,
+                                                             const int32_t *__restrict__ res,
+                                                             int32_t *__restrict__ part) {
+    // per-workgroup partial {minx, miny, maxx, maxy, zeroed, dirty} (plain stores, folded on the host)
+    int32_t *mypart = part + 6 * (blockIdx.y * gridDim.x + blockIdx.x);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = blockIdx.x * 256 + 4 * lane, X = qx0 + lx;
     const int lyb = blockIdx.y * 8 + wave;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) res[R_DONE] = 1;
-    // tile entirely outside the ROI (block-uniform)
-    if (qx0 + (int)blockIdx.x * 256 >= gx1 || qx0 + (int)blockIdx.x * 256 + 256 <= gx0 || qy0 + (int)blockIdx.y * 8 >= gy1 ||
-        qy0 + (int)blockIdx.y * 8 + 8 <= gy0)
-        return;
-    int minx = INT_MAX, miny = INT_MAX, maxx = -1, maxy = -1, zeroed = 0, dirty = 0;
-    if (lx < qw && X < gx1 && X + 4 > gx0) {
-        uint32_t pw[2][4], pr[2][4];
+    // every load of the lane is issued before anything depends on the result block (one memory round trip)
+    uint32_t pw[2][4], pr[2][4];
+    int T[4], B[4], L[2], R[2];
+    const int4 *rt = (const int4 *)rows;
+    if (lx < qw) {
 #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int ly = min(lyb + 4 * i, qh - 1);
             quad_load<C>(wbuf + (int64_t)ly * wpitch, lx, qw, pw[i]);
             quad_load<C>(mosaic_q + (int64_t)ly * mpitch, lx, qw, pr[i]);
+            const int4 e = rt[ly];
+            L[i] = e.z;
+            R[i] = e.w;
         }
-        const double f = (double)feather;
-        int T[4], B[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int xc = min(lx + k, qw - 1);
             T[k] = cols[xc];
             B[k] = cols[qw + xc];
         }
+    }
+    const int found = res[R_WBBOX + 4], rows_ok = res[R_ROWS_OK];
+    const int gx0 = res[R_ROI + 0], gy0 = res[R_ROI + 1], gx1 = res[R_ROI + 2], gy1 = res[R_ROI + 3];
+    // alpha = k / feather for k = 0 .. feather (proc.py:220, :225, :239, :244), divided once per workgroup:
+    // the same IEEE quotient as the reference's per-pixel division
+    __shared__ double ftab[64];
+    __shared__ int red[4][6];
+    if (threadIdx.x <= feather) ftab[threadIdx.x] = (double)(int)threadIdx.x / (double)feather;
+    if (threadIdx.x == 0) mypart[0] = mypart[1] = INT_MAX, mypart[2] = mypart[3] = -1, mypart[4] = mypart[5] = 0;
+    if (!found || !rows_ok) return;
+    // tile entirely outside the ROI (block-uniform)
+    if (qx0 + (int)blockIdx.x * 256 >= gx1 || qx0 + (int)blockIdx.x * 256 + 256 <= gx0 || qy0 + (int)blockIdx.y * 8 >= gy1 ||
+        qy0 + (int)blockIdx.y * 8 + 8 <= gy0)
+        return;
+    __syncthreads();
+    const bool active = lx < qw && X < gx1 && X + 4 > gx0;
+    bool feathered = false;
+    if (active) {
+        // does any pixel of this lane sit in a feather band (conservative: clipping only shrinks the bands)
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            const int ly = lyb + 4 * i, Y = qy0 + ly;
-            if (ly >= qh || Y < gy0 || Y >= gy1) continue;
-            const int L = rows[2 * qh + ly], R = rows[3 * qh + ly];
-            uint32_t po[4];
+            const int Y = qy0 + lyb + 4 * i;
+            if (R[i] >= 0 && ((X + 3 >= L[i] && X < L[i] + feather) || (X + 3 >= R[i] - feather && X <= R[i]))) feathered = true;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int xx = X + k;
-                po[k] = pr[i][k];
-                if (xx < gx0 || xx >= gx1 || lx + k >= qw) continue;
-                // factor chain of proc.py:211-246 in ROI-relative form: [L, min(L+f, W)) and [max(0, R-f), R]
-                double m = 1.0;
-                if (R >= 0) {
-                    const int xe = L + feather < gx1 ? L + feather : gx1;
-                    if (xx >= L && xx < xe) m *= (double)(xx - L) / f;
-                    const int xb = R - feather > gx0 ? R - feather : gx0;
-                    if (xx >= xb && xx <= R) m *= (double)(R - xx) / f;
+            for (int k = 0; k < 4; k++)
+                if (B[k] >= 0 && ((Y >= T[k] && Y < T[k] + feather) || (Y >= B[k] - feather && Y <= B[k]))) feathered = true;
+        }
+    }
+#ifdef ISX_DIAG_K3_NOSLOW
+    const bool slow = false;
+#else
+    const bool slow = __any(feathered);
+#endif
+    int minx = INT_MAX, miny = INT_MAX, maxx = -1, maxy = -1; // wave-uniform from here on
+    bool zeroed = false, dirty = false;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int ly = lyb + 4 * i, Y = qy0 + ly;
+        const bool row_in = ly < qh && Y >= gy0 && Y < gy1; // wave-uniform
+        if (!row_in) continue;
+        uint32_t po[4];
+        bool nz[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xx = X + k;
+            const bool in = active && xx >= gx0 && xx < gx1 && lx + k < qw;
+            uint32_t o = 0;
+            if (!slow) {
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const uint32_t wv = (pw[i][k] >> (8 * c)) & 255u, rv = (pr[i][k] >> (8 * c)) & 255u;
+                    o |= (wv ? wv : rv) << (8 * c);
                 }
-                if (B[k] >= 0) {
-                    const int ye = T[k] + feather < gy1 ? T[k] + feather : gy1;
-                    if (Y >= T[k] && Y < ye) m *= (double)(Y - T[k]) / f;
-                    const int yb = B[k] - feather > gy0 ? B[k] - feather : gy0;
-                    if (Y >= yb && Y <= B[k]) m *= (double)(B[k] - Y) / f;
-                }
-                uint32_t o = 0;
+            } else {
+                // factor chain of proc.py:211-246 in ROI-relative form: [L, min(L+f, W)) and [max(0, R-f), R].  Branch
+                // free: a factor that does not apply is read as ftab[feather] = 1.0 (an exact no-op), so the four
+                // LDS reads of a pixel are in flight together
+                const int xe = L[i] + feather < gx1 ? L[i] + feather : gx1, xb = R[i] - feather > gx0 ? R[i] - feather : gx0;
+                const int ye = T[k] + feather < gy1 ? T[k] + feather : gy1, yb = B[k] - feather > gy0 ? B[k] - feather : gy0;
+                const int i0 = (R[i] >= 0 && xx >= L[i] && xx < xe) ? xx - L[i] : feather;
+                const int i1 = (R[i] >= 0 && xx >= xb && xx <= R[i]) ? R[i] - xx : feather;
+                const int i2 = (B[k] >= 0 && Y >= T[k] && Y < ye) ? Y - T[k] : feather;
+                const int i3 = (B[k] >= 0 && Y >= yb && Y <= B[k]) ? B[k] - Y : feather;
+                const double m = ((ftab[i0] * ftab[i1]) * ftab[i2]) * ftab[i3];
 #pragma unroll
                 for (int c = 0; c < C; c++) {
                     const int wv = (pw[i][k] >> (8 * c)) & 255, rv = (pr[i][k] >> (8 * c)) & 255;
@@ -327,71 +634,68 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
                     const double r = (double)wv * mk + (double)rv * (1 - mk);
                     o |= (uint32_t)(uint8_t)(int)r << (8 * c);
                 }
-                po[k] = o;
-                const int go = gray_px<C>(o);
-                if (go != 0) {
-                    minx = min(minx, xx);
-                    maxx = max(maxx, xx + 1);
-                    miny = min(miny, Y);
-                    maxy = max(maxy, Y + 1);
-                } else {
-                    if (o != 0u) dirty++;
-                    if (gray_px<C>(pr[i][k]) != 0) zeroed++;
-                }
             }
-            quad_store<C>(mosaic_q + (int64_t)ly * mpitch, lx, qw, po);
+            po[k] = in ? o : pr[i][k];
+            const bool g = in && gray_px<C>(o) != 0;
+            nz[k] = g;
+            dirty = dirty || (in && !g && o != 0u);
+            zeroed = zeroed || (in && !g && gray_px<C>(pr[i][k]) != 0);
+        }
+        if (active) quad_store<C>(mosaic_q + (int64_t)ly * mpitch, lx, qw, po);
+        // bbox of the written gray != 0 pixels from ballots (bit l of word k = pixel 4*l + k of the chunk)
+        const int cx = qx0 + (int)blockIdx.x * 256;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t bm = __ballot(nz[k]);
+            if (bm) {
+                minx = min(minx, cx + 4 * (int)__builtin_ctzll(bm) + k);
+                maxx = max(maxx, cx + 4 * (63 - (int)__builtin_clzll(bm)) + k + 1);
+                miny = min(miny, Y);
+                maxy = max(maxy, Y + 1);
+            }
         }
     }
-    // merged bbox: only what extends the old mosaic's box [ox0,ox1) x [oy0,oy1) needs to be published
-    minx = wave_min(minx), miny = wave_min(miny), maxx = wave_max(maxx), maxy = wave_max(maxy);
-    if (lane == 0 && maxx >= 0) {
-        const bool have_old = ox1 > ox0;
-        if (!have_old || minx < ox0) atomicMin(&res[R_MBBOX + 0], minx);
-        if (!have_old || miny < oy0) atomicMin(&res[R_MBBOX + 1], miny);
-        if (!have_old || maxx > ox1) atomicMax(&res[R_MBBOX + 2], maxx);
-        if (!have_old || maxy > oy1) atomicMax(&res[R_MBBOX + 3], maxy);
-        if (!have_old || minx < ox0 || miny < oy0 || maxx > ox1 || maxy > oy1) res[R_MBBOX + 4] = 1;
-    }
-    const uint64_t bz = __ballot(zeroed != 0), bd = __ballot(dirty != 0);
-    if (bz | bd) {
-        for (int m = 1; m < 64; m <<= 1) {
-            zeroed += __shfl_xor(zeroed, m);
-            dirty += __shfl_xor(dirty, m);
+    const int zf = __any(zeroed), df = __any(dirty);
+    if (lane == 0)
+        red[wave][0] = minx, red[wave][1] = miny, red[wave][2] = maxx, red[wave][3] = maxy, red[wave][4] = zf, red[wave][5] = df;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a0 = red[0][0], a1 = red[0][1], a2 = red[0][2], a3 = red[0][3], a4 = red[0][4], a5 = red[0][5];
+        for (int w = 1; w < 4; w++) {
+            a0 = min(a0, red[w][0]);
+            a1 = min(a1, red[w][1]);
+            a2 = max(a2, red[w][2]);
+            a3 = max(a3, red[w][3]);
+            a4 |= red[w][4];
+            a5 |= red[w][5];
         }
-        if (lane == 0) {
-            if (zeroed) atomicAdd(&res[R_ZEROED], zeroed);
-            if (dirty) atomicAdd(&res[R_DIRTY], dirty);
-        }
+        mypart[0] = a0, mypart[1] = a1, mypart[2] = a2, mypart[3] = a3, mypart[4] = a4, mypart[5] = a5;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// alpha path K1: warp + seamless_merge in place over all of Q (outside Q the warped image is 0 and the merged
-// canvas equals the mosaic).  Per-row table (8 ints): warped gray extent, merged gray extent, zeroed, dirty.
+// alpha path: warp + seamless_merge in place over all of Q (outside Q the warped image is 0 and the merged
+// canvas equals the mosaic).  Per-row table (6 ints): warped gray extent, merged gray extent, zeroed, dirty.
 // ------------------------------------------------------------------------------------------------
 template <int C, bool PERSP, bool CLASSIC>
-__global__ void __launch_bounds__(256) frame_warp_alpha_kernel(const uint8_t *__restrict__ src, const WarpParams P,
+__global__ void __launch_bounds__(1024) frame_warp_alpha_kernel(const uint8_t *__restrict__ src, const WarpParams P,
                                                                uint8_t *mosaic_q, int64_t mpitch, int nchunk,
                                                                double contrib, double one_minus,
                                                                int32_t *__restrict__ rows) {
-    const int ly = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ly = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int gl = INT_MAX, gr = -1, ml = INT_MAX, mr = -1, zeroed = 0, dirty = 0;
     uint8_t *mrow = mosaic_q + (int64_t)ly * mpitch;
-    for (int chunk = wave; chunk < nchunk; chunk += 4) {
+    for (int chunk = wave; chunk < nchunk; chunk += nw) {
         const int lx = chunk * 256 + 4 * lane;
-        if (lx >= P.dw) continue;
-        uint32_t px[4], pb[4], po[4];
-        quad_load<C>(mrow, lx, P.dw, pb);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            px[i] = lx + i >= P.dw ? 0u
-                    : CLASSIC  ? warp_pixel_classic<C, PERSP>(src, P, P.dx0 + lx + i, P.dy0 + ly)
-                               : warp_pixel<C, PERSP>(src, P, P.dx0 + lx + i, P.dy0 + ly);
+        const int nv = min(4, max(0, P.dw - lx));
+        uint32_t px[4], pb[4] = {0u, 0u, 0u, 0u}, po[4];
+        if (nv > 0) quad_load<C>(mrow, lx, P.dw, pb);
+        warp_quad<C, PERSP, CLASSIC>(src, P, P.dx0 + lx, P.dy0 + ly, nv, px);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             po[i] = alpha_px<C>(px[i], pb[i], contrib, one_minus);
             const int X = P.dx0 + lx + i;
-            if (lx + i >= P.dw) continue;
+            if (i >= nv) continue;
             if (gray_px<C>(px[i]) != 0) {
                 gl = min(gl, X);
                 gr = max(gr, X);
@@ -400,81 +704,36 @@ __global__ void __launch_bounds__(256) frame_warp_alpha_kernel(const uint8_t *__
                 ml = min(ml, X);
                 mr = max(mr, X);
             } else {
-                if (po[i] != 0u) dirty++;
-                if (gray_px<C>(pb[i]) != 0) zeroed++;
+                if (po[i] != 0u) dirty = 1;
+                if (gray_px<C>(pb[i]) != 0) zeroed = 1;
             }
         }
-        quad_store<C>(mrow, lx, P.dw, po);
+        if (nv > 0) quad_store<C>(mrow, lx, P.dw, po);
     }
-    __shared__ int red[4][6];
+    __shared__ int red[FRAME_MAX_WAVES][6];
     gl = wave_min(gl), gr = wave_max(gr), ml = wave_min(ml), mr = wave_max(mr);
-    for (int m = 1; m < 64; m <<= 1) {
-        zeroed += __shfl_xor(zeroed, m);
-        dirty += __shfl_xor(dirty, m);
-    }
+    zeroed = wave_max(zeroed), dirty = wave_max(dirty);
     if (lane == 0)
         red[wave][0] = gl, red[wave][1] = gr, red[wave][2] = ml, red[wave][3] = mr, red[wave][4] = zeroed,
         red[wave][5] = dirty;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) {
+        for (int w = 1; w < nw; w++) {
             gl = min(gl, red[w][0]);
             gr = max(gr, red[w][1]);
             ml = min(ml, red[w][2]);
             mr = max(mr, red[w][3]);
-            zeroed += red[w][4];
-            dirty += red[w][5];
+            zeroed |= red[w][4];
+            dirty |= red[w][5];
         }
-        rows[ly] = gl;
-        rows[P.dh + ly] = gr;
-        rows[2 * P.dh + ly] = ml;
-        rows[3 * P.dh + ly] = mr;
-        rows[4 * P.dh + ly] = zeroed;
-        rows[5 * P.dh + ly] = dirty;
+        int32_t *o = rows + 6 * ly;
+        o[0] = gl, o[1] = gr, o[2] = ml, o[3] = mr, o[4] = zeroed, o[5] = dirty;
     }
 }
 
-__global__ void __launch_bounds__(256) frame_alpha_finish_kernel(const int32_t *__restrict__ rows, int qy0, int qh,
-                                                                 int32_t *__restrict__ res) {
-    __shared__ int red[4][4];
-    int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1, mx0 = INT_MAX, my0 = INT_MAX, mx1 = -1, my1 = -1, z = 0, d = 0;
-    for (int ly = threadIdx.x; ly < qh; ly += 256) {
-        const int gr = rows[qh + ly], mr = rows[3 * qh + ly];
-        if (gr >= 0) {
-            x0 = min(x0, rows[ly]);
-            x1 = max(x1, gr + 1);
-            y0 = min(y0, qy0 + ly);
-            y1 = max(y1, qy0 + ly + 1);
-        }
-        if (mr >= 0) {
-            mx0 = min(mx0, rows[2 * qh + ly]);
-            mx1 = max(mx1, mr + 1);
-            my0 = min(my0, qy0 + ly);
-            my1 = max(my1, qy0 + ly + 1);
-        }
-        z += rows[4 * qh + ly];
-        d += rows[5 * qh + ly];
-    }
-    block_minmax4(x0, y0, x1, y1, red);
-    block_minmax4(mx0, my0, mx1, my1, red);
-    int zz = 0, dd = 0, z2 = z > 0x3FFFFFFF ? 0x3FFFFFFF : z, d2 = d > 0x3FFFFFFF ? 0x3FFFFFFF : d;
-    block_minmax4(zz, dd, z2, d2, red); // max over threads is enough: the caller only tests != 0
-    if (threadIdx.x == 0) {
-        res[R_WBBOX + 0] = x0, res[R_WBBOX + 1] = y0, res[R_WBBOX + 2] = x1, res[R_WBBOX + 3] = y1;
-        res[R_WBBOX + 4] = x1 >= 0;
-        res[R_ROI + 0] = res[R_ROI + 1] = res[R_ROI + 2] = res[R_ROI + 3] = 0;
-        res[R_MBBOX + 0] = mx0, res[R_MBBOX + 1] = my0, res[R_MBBOX + 2] = mx1, res[R_MBBOX + 3] = my1;
-        res[R_MBBOX + 4] = mx1 >= 0;
-        res[R_ZEROED] = z2;
-        res[R_DIRTY] = d2;
-        res[R_ROWS_OK] = 1;
-        res[R_DONE] = 1;
-    }
-}
-
-static int fill_warp_params(WarpParams &P, const double *M_host, int model, int arith, int canvas_w, int canvas_h,
-                            int sh, int sw, int64_t spitch, int src_x, int src_y, int qx0, int qy0, int qw, int qh,
-                            int64_t dpitch) {
+static void fill_warp_params(WarpParams &P, const double *M_host, int model, int arith, int canvas_w, int canvas_h,
+                             int sh, int sw, int64_t spitch, int src_x, int src_y, int qx0, int qy0, int qw, int qh,
+                             int64_t dpitch) {
     double iM[9];
     if (model == ISX_MODEL_HOMOGRAPHY)
         invert_3x3_cv(M_host, iM);
@@ -489,55 +748,61 @@ static int fill_warp_params(WarpParams &P, const double *M_host, int model, int 
     P.src_x = src_x, P.src_y = src_y, P.sh = sh, P.sw = sw;
     P.dx0 = qx0, P.dy0 = qy0, P.dw = qw, P.dh = qh;
     P.spitch = spitch, P.dpitch = dpitch;
-    return ISX_OK;
+}
+
+static void empty_result(int32_t *r) {
+    memset(r, 0, R_INTS * 4);
+    r[R_WBBOX + 0] = r[R_WBBOX + 1] = r[R_MBBOX + 0] = r[R_MBBOX + 1] = INT_MAX;
+    r[R_WBBOX + 2] = r[R_WBBOX + 3] = r[R_MBBOX + 2] = r[R_MBBOX + 3] = -1;
+    r[R_ROWS_OK] = 1;
 }
 
 extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x,
                                int src_y, const double *M_host, int model, int arith, int canvas_w, int canvas_h,
-                               uint8_t *mosaic_q_dev, int64_t mpitch, int q_x0, int q_y0, int q_w, int q_h,
-                               const int32_t *old_bbox_host, int blender, double ref_contrib, int feather,
-                               int32_t *result_host, void *stream) {
-    ISX_REQUIRE(ctx && result_host, "null ctx / result_host");
+                               uint8_t *mosaic_q_dev, int64_t mpitch, int q_x0, int q_y0, int q_w, int q_h, int blender,
+                               double ref_contrib, int feather, int32_t *result_host, void *stream) {
+    ISX_REQUIRE(ctx, "null ctx");
     ISX_REQUIRE(c == 1 || c == 3, "channels must be 1 or 3 (got %d)", c);
     ISX_REQUIRE(model == ISX_MODEL_AFFINE_PARTIAL || model == ISX_MODEL_HOMOGRAPHY, "bad model %d", model);
     ISX_REQUIRE(arith == ISX_WARP_LINEAR_F32 || arith == ISX_WARP_CLASSIC, "bad warp arithmetic %d", arith);
     ISX_REQUIRE(blender == ISX_BLEND_ALPHA || blender == ISX_BLEND_GRADIENT, "bad blender %d", blender);
     ISX_REQUIRE(M_host, "null M_host");
-    ISX_REQUIRE(sh > 0 && sw > 0 && spitch >= (int64_t)sw * c, "bad source geometry");
+    ISX_REQUIRE(sh > 0 && sw > 1 && spitch >= (int64_t)sw * c, "bad source geometry (the frame must be at least 2 pixels wide)");
+    ISX_REQUIRE((int64_t)sh * spitch < ((int64_t)1 << 31), "the frame must be smaller than 2 GiB (the mosaic may be larger)");
     ISX_REQUIRE(canvas_w > 0 && canvas_h > 0 && q_x0 >= 0 && q_y0 >= 0 && q_w >= 0 && q_h >= 0 &&
                     q_x0 + q_w <= canvas_w && q_y0 + q_h <= canvas_h,
                 "Q = (%d,%d %dx%d) outside the %dx%d canvas", q_x0, q_y0, q_w, q_h, canvas_w, canvas_h);
     ISX_REQUIRE(q_w <= ISX_FRAME_MAX_Q && q_h <= ISX_FRAME_MAX_Q, "Q larger than %d pixels on a side", ISX_FRAME_MAX_Q);
-    ISX_REQUIRE(blender == ISX_BLEND_ALPHA || feather > 0, "feather must be positive");
+    ISX_REQUIRE(blender == ISX_BLEND_ALPHA || (feather > 0 && feather < 64), "feather must be in 1..63");
     int cur = -1;
     ISX_HIP_TRY(hipGetDevice(&cur));
     ISX_REQUIRE(cur == ctx->device, "ctx belongs to device %d but device %d is current", ctx->device, cur);
     hipStream_t st = (hipStream_t)stream;
-    int32_t *r = result_host;
+    ctx->pending = 0;
     if (q_w == 0 || q_h == 0) { // nothing of the frame lands on the canvas
-        memset(r, 0, R_INTS * 4);
-        r[R_WBBOX + 0] = r[R_WBBOX + 1] = r[R_MBBOX + 0] = r[R_MBBOX + 1] = INT_MAX;
-        r[R_WBBOX + 2] = r[R_WBBOX + 3] = r[R_MBBOX + 2] = r[R_MBBOX + 3] = -1;
-        r[R_ROWS_OK] = 1;
+        empty_result(ctx->last);
+        if (result_host) memcpy(result_host, ctx->last, R_INTS * 4);
         return ISX_OK;
     }
     ISX_REQUIRE(src_dev && mosaic_q_dev && mpitch >= (int64_t)q_w * c, "null device pointer / bad mosaic pitch");
-    int ob[4] = {0, 0, 0, 0};
-    if (old_bbox_host) memcpy(ob, old_bbox_host, sizeof(ob));
     const int nchunk = (q_w + 255) / 256;
+    const int row_threads = 64 * (nchunk < FRAME_MAX_WAVES ? nchunk : FRAME_MAX_WAVES);
     const bool persp = model == ISX_MODEL_HOMOGRAPHY, classic = arith == ISX_WARP_CLASSIC;
     int rc;
     WarpParams P;
     if (blender == ISX_BLEND_GRADIENT) {
         const int64_t wpitch = (int64_t)q_w * c;
+        dim3 gb(nchunk, (q_h + 7) / 8);
+        const int n_part = (int)(gb.x * gb.y);
         if ((rc = ctx_ensure(&ctx->wbuf, &ctx->wbuf_cap, (size_t)wpitch * q_h + 16)) != ISX_OK) return rc;
-        if ((rc = ctx_ensure(&ctx->rows, &ctx->rows_cap, (size_t)8 * q_h)) != ISX_OK) return rc;
+        if ((rc = ctx_ensure(&ctx->rows, &ctx->rows_cap, (size_t)4 * q_h)) != ISX_OK) return rc;
         if ((rc = ctx_ensure(&ctx->cols, &ctx->cols_cap, (size_t)2 * q_w)) != ISX_OK) return rc;
         if ((rc = ctx_ensure(&ctx->mask, &ctx->mask_cap, (size_t)q_h * nchunk * 4)) != ISX_OK) return rc;
+        if ((rc = ctx_ensure_out(ctx, (size_t)R_INTS + (size_t)6 * n_part)) != ISX_OK) return rc;
         fill_warp_params(P, M_host, model, arith, canvas_w, canvas_h, sh, sw, spitch, src_x, src_y, q_x0, q_y0, q_w, q_h, wpitch);
-#define ISX_FW_LAUNCH(CC, PP, AA)                                                                                   \
-    hipLaunchKernelGGL((frame_warp_kernel<CC, PP, AA>), dim3(q_h), dim3(256), 0, st, src_dev, P, ctx->wbuf, nchunk, \
-                       ctx->rows, ctx->mask, ctx->cols)
+#define ISX_FW_LAUNCH(CC, PP, AA)                                                                                \
+    hipLaunchKernelGGL((frame_warp_kernel<CC, PP, AA>), dim3(q_h), dim3(row_threads), 0, st, src_dev, P, ctx->wbuf, \
+                       nchunk, ctx->rows, ctx->mask)
         if (c == 3) {
             if (persp && classic) ISX_FW_LAUNCH(3, true, true);
             else if (persp) ISX_FW_LAUNCH(3, true, false);
@@ -550,22 +815,23 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
             else ISX_FW_LAUNCH(1, false, false);
         }
 #undef ISX_FW_LAUNCH
-        hipLaunchKernelGGL(frame_extent_kernel, dim3(nchunk, (q_h + 63) / 64), dim3(256), 0, st, ctx->rows, q_x0, q_y0, q_w,
-                           q_h, canvas_w, canvas_h, 50, ctx->mask, nchunk, ctx->cols, ctx->res_dev);
-        dim3 gb(nchunk, (q_h + 7) / 8);
+        hipLaunchKernelGGL(frame_extent_kernel, dim3(nchunk), dim3(1024), 0, st, ctx->rows, q_x0, q_y0, q_w, q_h, canvas_w,
+                           canvas_h, 50, ctx->mask, nchunk, ctx->cols, ctx->out_dev);
         if (c == 3)
             hipLaunchKernelGGL((frame_gradient_kernel<3>), gb, dim3(256), 0, st, ctx->wbuf, wpitch, mosaic_q_dev, mpitch, q_x0,
-                               q_y0, q_w, q_h, ctx->rows, ctx->cols, feather, ob[0], ob[1], ob[2], ob[3], ctx->res_dev);
+                               q_y0, q_w, q_h, ctx->rows, ctx->cols, feather, ctx->out_dev, ctx->out_dev + R_INTS);
         else
             hipLaunchKernelGGL((frame_gradient_kernel<1>), gb, dim3(256), 0, st, ctx->wbuf, wpitch, mosaic_q_dev, mpitch, q_x0,
-                               q_y0, q_w, q_h, ctx->rows, ctx->cols, feather, ob[0], ob[1], ob[2], ob[3], ctx->res_dev);
+                               q_y0, q_w, q_h, ctx->rows, ctx->cols, feather, ctx->out_dev, ctx->out_dev + R_INTS);
+        ctx->fold_n = n_part;
+        ctx->pending = 1;
     } else {
-        if ((rc = ctx_ensure(&ctx->rows, &ctx->rows_cap, (size_t)8 * q_h)) != ISX_OK) return rc;
+        if ((rc = ctx_ensure_out(ctx, (size_t)R_INTS + (size_t)6 * q_h)) != ISX_OK) return rc;
         fill_warp_params(P, M_host, model, arith, canvas_w, canvas_h, sh, sw, spitch, src_x, src_y, q_x0, q_y0, q_w, q_h, mpitch);
         const double one_minus = 1 - ref_contrib; // Python: (1-ref_image_contrib)
-#define ISX_FA_LAUNCH(CC, PP, AA)                                                                                      \
-    hipLaunchKernelGGL((frame_warp_alpha_kernel<CC, PP, AA>), dim3(q_h), dim3(256), 0, st, src_dev, P, mosaic_q_dev, mpitch, \
-                       nchunk, ref_contrib, one_minus, ctx->rows)
+#define ISX_FA_LAUNCH(CC, PP, AA)                                                                                     \
+    hipLaunchKernelGGL((frame_warp_alpha_kernel<CC, PP, AA>), dim3(q_h), dim3(row_threads), 0, st, src_dev, P, mosaic_q_dev, \
+                       mpitch, nchunk, ref_contrib, one_minus, ctx->out_dev + R_INTS)
         if (c == 3) {
             if (persp && classic) ISX_FA_LAUNCH(3, true, true);
             else if (persp) ISX_FA_LAUNCH(3, true, false);
@@ -578,12 +844,65 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
             else ISX_FA_LAUNCH(1, false, false);
         }
 #undef ISX_FA_LAUNCH
-        hipLaunchKernelGGL(frame_alpha_finish_kernel, dim3(1), dim3(256), 0, st, ctx->rows, q_y0, q_h, ctx->res_dev);
+        ctx->fold_n = q_h;
+        ctx->fold_qy0 = q_y0;
+        ctx->pending = 2;
     }
     if ((rc = isx_launch_status("frame kernels")) != ISX_OK) return rc;
-    ISX_HIP_TRY(hipMemcpyAsync(ctx->res_host, ctx->res_dev, R_INTS * 4, hipMemcpyDeviceToHost, st));
-    ISX_HIP_TRY(hipStreamSynchronize(st));
-    memcpy(r, ctx->res_host, R_INTS * 4);
+    if (!result_host) return ISX_OK; // queued only: the caller fetches the result block with isx_frame_result
+    return isx_frame_result(ctx, result_host, stream);
+}
+
+extern "C" int isx_frame_result(isx_ctx *ctx, int32_t *result_host, void *stream) {
+    ISX_REQUIRE(ctx && result_host, "null ctx / result_host");
+    if (ctx->pending) {
+        hipStream_t st = (hipStream_t)stream;
+        const size_t ints = (size_t)R_INTS + (size_t)6 * ctx->fold_n;
+        ISX_HIP_TRY(hipMemcpyAsync(ctx->out_host, ctx->out_dev, ints * 4, hipMemcpyDeviceToHost, st));
+        ISX_HIP_TRY(hipStreamSynchronize(st));
+        int32_t *r = ctx->last;
+        const int32_t *t = ctx->out_host + R_INTS;
+        empty_result(r);
+        if (ctx->pending == 1) { // gradient: K2's block + the fold of K3's partials
+            memcpy(r, ctx->out_host, (R_ROI + 4) * 4);
+            r[R_ROWS_OK] = ctx->out_host[R_ROWS_OK];
+            for (int i = 0; i < ctx->fold_n; i++, t += 6) {
+                if (t[2] >= 0) {
+                    if (t[0] < r[R_MBBOX + 0]) r[R_MBBOX + 0] = t[0];
+                    if (t[1] < r[R_MBBOX + 1]) r[R_MBBOX + 1] = t[1];
+                    if (t[2] > r[R_MBBOX + 2]) r[R_MBBOX + 2] = t[2];
+                    if (t[3] > r[R_MBBOX + 3]) r[R_MBBOX + 3] = t[3];
+                }
+                r[R_ZEROED] |= t[4];
+                r[R_DIRTY] |= t[5];
+            }
+            r[R_MBBOX + 4] = r[R_MBBOX + 2] >= 0;
+            r[R_DONE] = r[R_WBBOX + 4] && r[R_ROWS_OK];
+        } else { // alpha: the fold of the row table
+            for (int i = 0; i < ctx->fold_n; i++, t += 6) {
+                const int y = ctx->fold_qy0 + i;
+                if (t[1] >= 0) {
+                    if (t[0] < r[R_WBBOX + 0]) r[R_WBBOX + 0] = t[0];
+                    if (t[1] + 1 > r[R_WBBOX + 2]) r[R_WBBOX + 2] = t[1] + 1;
+                    if (y < r[R_WBBOX + 1]) r[R_WBBOX + 1] = y;
+                    r[R_WBBOX + 3] = y + 1;
+                }
+                if (t[3] >= 0) {
+                    if (t[2] < r[R_MBBOX + 0]) r[R_MBBOX + 0] = t[2];
+                    if (t[3] + 1 > r[R_MBBOX + 2]) r[R_MBBOX + 2] = t[3] + 1;
+                    if (y < r[R_MBBOX + 1]) r[R_MBBOX + 1] = y;
+                    r[R_MBBOX + 3] = y + 1;
+                }
+                r[R_ZEROED] |= t[4];
+                r[R_DIRTY] |= t[5];
+            }
+            r[R_WBBOX + 4] = r[R_WBBOX + 2] >= 0;
+            r[R_MBBOX + 4] = r[R_MBBOX + 2] >= 0;
+            r[R_DONE] = 1;
+        }
+        ctx->pending = 0;
+    }
+    memcpy(result_host, ctx->last, R_INTS * 4);
     return ISX_OK;
 }
 

@@ -514,7 +514,6 @@ class FrameCtx:
             check(_lib.lib().isx_ctx_create(ctypes.byref(h)))
         self._h = h
         self._res = np.zeros((_lib.FRAME_RESULT_INTS,), np.int32)
-        self._old = np.zeros((4,), np.int32)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -525,12 +524,12 @@ class FrameCtx:
                 pass
 
 
-def frame_blend(ctx, src, M, perspective, src_xy, canvas_wh, arena_t, canvas_to_arena, q_rect, old_bbox, blender,
+def frame_blend(ctx, src, M, perspective, src_xy, canvas_wh, arena_t, canvas_to_arena, q_rect, blender,
                 contrib=0.5, feather=10, arith="f32"):
     """isx_frame_blend: warp `src` (pasted at src_xy of the virtual canvas) by M and blend it IN PLACE into the
     mosaic held by arena_t (canvas (X, Y) is arena pixel (X + canvas_to_arena[0], Y + canvas_to_arena[1])), only over
-    the canvas rectangle q_rect = (x0, y0, w, h).  old_bbox: (x0,y0,x1,y1) canvas bbox of the mosaic's gray != 0
-    pixels or None.  Synchronous; returns the int32 result block as a dict of python ints / tuples."""
+    the canvas rectangle q_rect = (x0, y0, w, h).  Synchronous; returns the int32 result block as a dict of python
+    ints / tuples."""
     p, sh, sw, c, spitch = _img_args(src, "src")
     pa, ah, aw, ac, apitch = _img_args(arena_t, "arena")
     if ac != c:
@@ -542,11 +541,6 @@ def frame_blend(ctx, src, M, perspective, src_xy, canvas_wh, arena_t, canvas_to_
     M = np.ascontiguousarray(M, np.float64)
     if M.shape != ((3, 3) if perspective else (2, 3)):
         raise IsxError(f"M has shape {M.shape}")
-    if old_bbox:
-        ctx._old[:] = old_bbox
-        ob = ctx._old.ctypes.data_as(ctypes.c_void_p)
-    else:
-        ob = None
     mq = ctypes.c_void_p(arena_t.data_ptr() + ay0 * apitch + ax0 * c)
     r = ctx._res
     with torch.cuda.device(src.device):
@@ -554,7 +548,7 @@ def frame_blend(ctx, src, M, perspective, src_xy, canvas_wh, arena_t, canvas_to_
                                          M.ctypes.data_as(ctypes.c_void_p),
                                          _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL,
                                          WARP_ARITH[arith], int(canvas_wh[0]), int(canvas_wh[1]), mq, apitch, qx0, qy0, qw, qh,
-                                         ob, int(blender), float(contrib), int(feather),
+                                         int(blender), float(contrib), int(feather),
                                          r.ctypes.data_as(ctypes.c_void_p), _stream()))
     v = r.tolist()
     return {"wbbox": tuple(v[0:4]) if v[4] else False, "roi": tuple(v[5:9]), "mbbox": tuple(v[9:13]), "mfound": bool(v[13]),

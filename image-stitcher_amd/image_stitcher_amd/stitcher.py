@@ -412,9 +412,8 @@ class Stitcher:
             cax, cay = cax + dx, cay + dy
             self.frame_stats["arena_allocs"] += arena.t is not t_before
         old = arena.bbox
-        old_c = (old[0] - cax, old[1] - cay, old[2] - cax, old[3] - cay) if old else None
         res = ops.frame_blend(self._frame_ctx(), img_d.t, M, self.type == 1, (ox, oy), (W, H), arena.t, (cax, cay),
-                              (qx0, qy0, qw, qh), old_c, self.blender, self.ref_image_contrib, 10, self.warp_arith)
+                              (qx0, qy0, qw, qh), self.blender, self.ref_image_contrib, 10, self.warp_arith)
         wb = res["wbbox"]
         wcorners = ((wb[0], wb[1]), (wb[2], wb[3])) if wb else False
         written = None  # canvas rectangle whose mosaic pixels were rewritten
@@ -444,11 +443,11 @@ class Stitcher:
             new = (int(bb[0]) + ux0, int(bb[1]) + uy0, int(bb[2]) + ux0, int(bb[3]) + uy0) if bb[4] else False
         else:
             mb = res["mbbox"]
-            if old:
-                new = (min(old[0], mb[0] + cax) if mb[0] < 2 ** 30 else old[0], min(old[1], mb[1] + cay) if mb[1] < 2 ** 30 else old[1],
-                       max(old[2], mb[2] + cax) if mb[2] >= 0 else old[2], max(old[3], mb[3] + cay) if mb[3] >= 0 else old[3])
-            else:
-                new = (mb[0] + cax, mb[1] + cay, mb[2] + cax, mb[3] + cay) if res["mfound"] else False
+            new = (mb[0] + cax, mb[1] + cay, mb[2] + cax, mb[3] + cay) if res["mfound"] else False
+            if old and new:
+                new = (min(old[0], new[0]), min(old[1], new[1]), max(old[2], new[2]), max(old[3], new[3]))
+            elif old:
+                new = old
         if new is False:
             return None, wcorners
         if arena.dirty or res["dirty"] or rescan or res["zeroed"]:

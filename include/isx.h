@@ -239,27 +239,27 @@ int isx_ctx_destroy(isx_ctx *ctx);
  *   Q = [q_x0, q_x0+q_w) x [q_y0, q_y0+q_h) : a canvas rectangle that contains every warped pixel that can be
  *       non-zero, plus >= 52 px on every side for the gradient blender's ROI (clipped to the canvas);
  *   mosaic_q_dev / mpitch : the arena pixel under canvas (q_x0, q_y0); all of Q must lie inside the arena;
- *   old_bbox_host : {x0,y0,x1,y1} bbox of the mosaic's gray != 0 pixels before the call, canvas coordinates
- *       (x1 <= x0: none); only used to skip publishing boxes that cannot extend it;
  *   blender / ref_contrib / feather : stitcher.py:153-156, utils/proc.py:48 `image1_contribution`, :192 (10).
- * The mosaic is updated IN PLACE.  SYNCHRONOUS: returns after the kernels finished, with result_host
- * (ISX_FRAME_RESULT_INTS int32) =
+ * The mosaic is updated IN PLACE.  SYNCHRONOUS when result_host is given: returns after the kernels finished
+ * (one small device-to-host copy + stream synchronisation).  With result_host == NULL the kernels are only
+ * queued (graph capture, back-to-back timing) and isx_frame_result fetches the block later from the same stream.
+ * result_host (ISX_FRAME_RESULT_INTS int32) =
  *   [0..4]   bbox of the warped image's gray != 0 pixels {x0,y0,x1,y1,found}            (stitcher.py:220)
  *   [5..8]   the gradient blender's ROI {x0,y0,x1,y1}                                  (utils/proc.py:199-201)
- *   [9..13]  bbox of the gray != 0 pixels written into the mosaic, found flag; with old_bbox given only the
- *            components that extend it are meaningful (the others stay INT_MAX / -1): the merged canvas's
- *            bbox (stitcher.py:225 crop_image) is the component-wise union with old_bbox ...
- *   [14]     ... provided this count is 0: pixels whose gray was != 0 and became 0 (else rescan the arena)
- *   [15]     pixels written with gray == 0 but a non-zero byte: if any lies outside the new bbox the caller
- *            must clear it (the reference's crop drops it, the next padded canvas has 0 there)
+ *   [9..13]  bbox of the gray != 0 pixels written into the mosaic + found flag: the merged canvas's bbox
+ *            (stitcher.py:225 crop_image) is its union with the bbox the mosaic had before ...
+ *   [14]     ... provided this flag is 0: some pixel's gray was != 0 and became 0 (else rescan the arena)
+ *   [15]     != 0: some pixel was written with gray == 0 but a non-zero byte: if it lies outside the new bbox the
+ *            caller must clear it (the reference's crop drops it, the next padded canvas has 0 there)
  *   [16]     gradient: 1 unless a channel-0 != 0 pixel of an ROI row lies outside the ROI's columns; when 0
  *            the mosaic was NOT touched ([17] == 0) and the caller blends the ROI with isx_gradient_blend from
  *            the staged warped image (isx_frame_warped)
  *   [17]     1 if the blend ran */
 int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
                     const double *M_host, int model, int arith, int canvas_w, int canvas_h, uint8_t *mosaic_q_dev,
-                    int64_t mpitch, int q_x0, int q_y0, int q_w, int q_h, const int32_t *old_bbox_host, int blender,
-                    double ref_contrib, int feather, int32_t *result_host, void *stream);
+                    int64_t mpitch, int q_x0, int q_y0, int q_w, int q_h, int blender, double ref_contrib, int feather,
+                    int32_t *result_host, void *stream);
+int isx_frame_result(isx_ctx *ctx, int32_t *result_host, void *stream);
 /* Device address of the warped image staged by the last gradient-path isx_frame_blend (Q-sized, pitch q_w * c). */
 int isx_frame_warped(isx_ctx *ctx, const uint8_t **wbuf_dev_out);
 

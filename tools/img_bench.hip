@@ -62,6 +62,24 @@ int main() {
         IK(isx_warp_alpha_blend(src, sh, sw, C, sw * C, sx, sy, M, 0, roi, dw * C, roi, dw * C, dx0, dy0, dw, dh, 0, 0, 0, 0.5, bb, 0));
     });
     printf("frame: FUSED warp+alpha+bbox    %7.2f us  algorithmic %6.0f GB/s\n", t, (src_b + 2 * roi_b) / t / 1e3);
+    // the per-frame entry point on a resident arena: Q = the same 2030x1190 region inside a 3-frame-wide canvas
+    {
+        isx_ctx *ctx; IK(isx_ctx_create(&ctx));
+        const int CW = 3 * 1920, CH = 3 * 1080;
+        uint8_t *arena; CK(hipMalloc(&arena, (size_t)CW * CH * C)); CK(hipMemset(arena, 0, (size_t)CW * CH * C));
+        CK(hipMemset2D(arena + ((size_t)1080 * CW + 1920) * C, (size_t)CW * C, 90, (size_t)1920 * C, 1080)); // the mosaic = one frame
+        int32_t res[ISX_FRAME_RESULT_INTS];
+        uint8_t *mq = arena + ((size_t)dy0 * CW + dx0) * C;
+        for (int blender = 1; blender >= 0; blender--) {
+            t = time_us(200, [&] { IK(isx_frame_blend(ctx, src, sh, sw, C, sw * C, sx, sy, M, 0, 0, CW, CH, mq, (int64_t)CW * C, dx0, dy0, dw, dh, blender, 0.5, 10, nullptr, 0)); });
+            IK(isx_frame_result(ctx, res, 0));
+            printf("frame: isx_frame_blend %-8s %7.2f us  algorithmic %6.0f GB/s  (wbbox %d,%d-%d,%d roi %d,%d-%d,%d done %d rows_ok %d zeroed %d)\n",
+                   blender ? "gradient" : "alpha", t, (src_b + 2 * roi_b) / t / 1e3, res[0], res[1], res[2], res[3], res[5], res[6], res[7], res[8], res[17], res[16], res[14]);
+        }
+        t = time_us(50, [&] { IK(isx_frame_blend(ctx, src, sh, sw, C, sw * C, sx, sy, M, 0, 0, CW, CH, mq, (int64_t)CW * C, dx0, dy0, dw, dh, 1, 0.5, 10, res, 0)); });
+        printf("frame: isx_frame_blend gradient, synchronous (with result read-back) %7.2f us per call\n", t);
+        IK(isx_ctx_destroy(ctx));
+    }
     t = time_us(200, [&] { CK(hipMemcpyAsync(roi, wbuf, (size_t)dw * dh * C, hipMemcpyDeviceToDevice, 0)); });
     printf("memcpy d2d roi        %7.2f us  %6.0f GB/s (read + write)\n", t, 2 * roi_b / t / 1e3);
     return 0;
