@@ -15,7 +15,7 @@ when the timed region starts.  The pair space is fixed and split over the ranks 
 "strong".
 
 The JSON line also carries:
-  roofline     -- the dominant kernel (knn2_count_kernel<4, 0>) against the dense int8 MFMA peak, from the
+  roofline     -- the dominant kernel (knn2_count16_kernel) against the dense int8 MFMA peak, from the
                   kernel duration measured live with HIP events around the launch;
   cpu_baseline -- the CPU oracle's port of cv2.BFMatcher().knnMatch(float32) + ratio loop, timed on
                   a bounded sample of the same pairs on this host (rank 0, N=1 only);
@@ -58,16 +58,29 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s mea
 
 
 class _TimedDetector:
-    """Wraps the CPU feature detector (out of scope, stays on the CPU as in the reference) to account its time."""
+    """Wraps the CPU feature detector (out of scope, stays on the CPU as in the reference) to account its time.
+    With record=True every result is kept; replay() then turns the object into a zero-cost detector that hands the
+    recorded results back in order, so that the SAME stream can be run again with detection taken out."""
 
-    def __init__(self, det):
+    def __init__(self, det, record=False):
         self.det, self.seconds, self.calls = det, 0.0, 0
+        self.log = [] if record else None
+        self._replay = None
+
+    def replay(self):
+        self._replay = iter(self.log)
+        self.seconds, self.calls = 0.0, 0
 
     def detectAndCompute(self, image, mask=None):
+        if self._replay is not None:
+            self.calls += 1
+            return next(self._replay)
         t0 = time.perf_counter()
         r = self.det.detectAndCompute(image, mask)
         self.seconds += time.perf_counter() - t0
         self.calls += 1
+        if self.log is not None:
+            self.log.append(r)
         return r
 
 
@@ -89,7 +102,7 @@ def stitch_workload(dev, n_frames):
         from image_stitcher_amd.detect import NumpyOrbLite
         new_det = lambda: NumpyOrbLite(nfeatures=1500)
         det, det_name = new_det(), "NumpyOrbLite (numpy/scipy stand-in, cv2 absent)"
-    det = _TimedDetector(det)
+    det = _TimedDetector(det, record=True)
     world = procedural_world(seed=42, h=2160, w=1920 + int(0.15 * 1920 * (n_frames + 4)) + 400)
     frames, _ = crop_path(world, n_frames + 3, (1080, 1920), step_frac=0.15, max_rot_deg=1.0, seed=43)
     warm = 3
@@ -102,6 +115,7 @@ def stitch_workload(dev, n_frames):
             st.stitch_consecutive(f)
         torch.cuda.synchronize()
         det.seconds, det.calls = 0.0, 0
+        st.phase_seconds.clear()
         ok = 0
         t0 = time.perf_counter()
         for f in frames[warm:]:
@@ -114,50 +128,50 @@ def stitch_workload(dev, n_frames):
     st_par, ok_par, wall_par = stream((det.det, new_det()), parallel_detect=True)
     st, ok, wall = stream(det)
     same = bool(torch.equal(st.refs[-1].t, st_par.refs[-1].t))
-    # kernel-level roofline of warp + feather blend on one representative 1080p frame (HIP events on the
-    # launch stream): algorithmic bytes = frame read + mosaic ROI read + write
+    live = dict(seconds=det.seconds, calls=det.calls, phases=dict(st.phase_seconds), stats=dict(st.frame_stats))
+    # the same stream once more with the recorded detections replayed at no cost: everything the stitching core does per
+    # frame (upload, frame bbox, region download for the detector, matching, RANSAC, warp + blend, bookkeeping), measured
+    # directly instead of as a difference of two large numbers
+    det.replay()
+    st_rp, ok_rp, wall_rp = stream(det)
+    same_rp = bool(torch.equal(st.refs[-1].t, st_rp.refs[-1].t))
+    replay_phases = dict(st_rp.phase_seconds)
+    det.seconds, det.calls = live["seconds"], live["calls"]
+    # kernel-level roofline of warp + feather blend on one representative 1080p frame: the launches of ONE
+    # isx_frame_blend call (frame_warp_kernel, frame_extent_kernel, frame_gradient_kernel), queued back to back
+    # between two HIP events on the launch stream.  Algorithmic bytes = frame read + mosaic read + write inside
+    # the warped frame's region; executed = + the staged warped image written once and read once.
     img = torch.from_numpy(frames[-1]).to(dev)
     H, W = 1080 * 3, 1920 * 3
     M = np.array([[0.9998, -0.0175, 300.0], [0.0175, 0.9998, 12.0]])
     rect = (1920 + 250, 1080 - 40, 2030, 1190)
-    wbuf = torch.empty((rect[3], rect[2], 3), dtype=torch.uint8, device=dev)
-    roi = torch.full((rect[3], rect[2], 3), 90, dtype=torch.uint8, device=dev)
+    arena = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    arena[1080:2160, 1920:3840] = 90
+    ctx = ops.FrameCtx(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 50
-    bb = ops.new_bbox(dev)
-    ext = torch.empty((2 * rect[3] + 2 * rect[2],), dtype=torch.int32, device=dev)
 
-    def frame_kernels():  # exactly the launches Stitcher.stitch issues per frame for warp + feather blend
-        ops.reset_bbox(bb)
-        ops.warp(img, M, False, rect, src_xy=(1920, 1080), out=wbuf, bbox=bb)
-        ops.gradient_blend_roi(wbuf, roi, ext=ext)
+    def frame_kernels():  # exactly the launches Stitcher.stitch issues per frame for warp + feather blend + both bboxes
+        ops.frame_blend(ctx, img, M, False, (1920, 1080), (W, H), arena, (0, 0), rect, 1, 0.2, 10, "f32", fetch=False)
 
     for _ in range(3):
         frame_kernels()
+    fr = ops.frame_result(ctx)
+    assert fr["done"] and fr["rows_ok"] and fr["wbbox"], fr
+    timing = "back-to-back launches between two HIP events (no host gaps: the queue stays ahead of the GPU)"
     torch.cuda.synchronize()
-    timing = "hipGraph replay (kernels back to back)"
-    try:
-        side = torch.cuda.Stream()
-        with torch.cuda.stream(side):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                frame_kernels()
-            g.replay()
-            torch.cuda.synchronize()
-            e0.record(side)
-            for _ in range(reps):
-                g.replay()
-            e1.record(side)
-        torch.cuda.synchronize()
-    except Exception as exc:  # capture unavailable: eager loop (host launch gaps included)
-        timing = f"eager loop, launch-bound ({type(exc).__name__})"
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            frame_kernels()
-        e1.record()
-        torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        frame_kernels()
+    e1.record()
+    torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
+    # the synchronous form Stitcher.stitch calls (kernels + one read-back + host fold)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ops.frame_blend(ctx, img, M, False, (1920, 1080), (W, H), arena, (0, 0), rect, 1, 0.2, 10, "f32")
+    sync_us = (time.perf_counter() - t0) / reps * 1e6
+    roi_px = rect[2] * rect[3] * 3
     # the same frame through the reference's own sequence on the CPU (stitcher.py:178-179, :216-225: pad both
     # images into the canvas, corners of the frame, warp the padded frame to canvas size, gradient merge,
     # corners of the warped image, crop), restated by the oracle -- one frame, it takes seconds
@@ -174,13 +188,19 @@ def stitch_workload(dev, n_frames):
     refc[gy0:gy1, gx0:gx1] = orc.gradient_blend(warped[gy0:gy1, gx0:gx1], refc[gy0:gy1, gx0:gx1], 10)
     orc.bbox_nonzero(refc)
     cpu_frame_s = time.perf_counter() - t0
-    alg_bytes = img.numel() + 2 * roi.numel()
-    executed_bytes = img.numel() + 2 * wbuf.numel() + 2 * roi.numel() + roi.numel()  # warp writes, extents+blend read wbuf
+    alg_bytes = img.numel() + 2 * roi_px
+    executed_bytes = img.numel() + 2 * roi_px + 2 * roi_px  # + the staged warped image, written once and read once
     return {
         "metric": "HD consecutive stitch Hz", "value": k / wall, "unit": "frames/s",
         "frames": k, "stitched": int(ok), "ms_per_frame": wall / k * 1e3,
         "detector": det_name, "detector_ms_per_frame": det.seconds / k * 1e3, "detector_calls": det.calls,
-        "hz_excluding_cpu_detection": k / max(wall - det.seconds, 1e-9),
+        "hz_excluding_cpu_detection": k / max(wall_rp, 1e-9),
+        "hz_excluding_cpu_detection_how": "the same stream re-run with the recorded detections replayed at zero cost "
+                                          f"({wall_rp / k * 1e3:.3f} ms per frame, same mosaic: {same_rp}); as a difference "
+                                          f"(wall - detector seconds) of the live run: {k / max(wall - det.seconds, 1e-9):.1f}",
+        "frame_stats": live["stats"],
+        "phase_ms_per_frame": {n: v / k * 1e3 for n, v in live["phases"].items()},
+        "phase_ms_per_frame_replayed": {n: v / k * 1e3 for n, v in replay_phases.items()},
         "parallel_detect": {"value": k / wall_par, "unit": "frames/s", "stitched": int(ok_par), "same_mosaic": same},
         "cpu_baseline": {"value": 1.0 / cpu_frame_s, "unit": "frames/s excluding detection", "cores": 1, "kind": "port",
                          "sample": f"1 frame: pad + warp + gradient merge + 3 bboxes on the {Wc}x{Hc} canvas as the reference "
@@ -190,9 +210,9 @@ def stitch_workload(dev, n_frames):
                    "final_mosaic_shape": [int(v) for v in st.refs[-1].shape]},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "bbox_init + warp_kernel<3,false> + bbox_finish + ext_init + row/col_extent + "
-                               "gradient_blend_kernel<3> (the 7 launches of one frame)",
-                     "kernel_us": us, "timing": timing, "algorithmic_bytes": int(alg_bytes), "executed_bytes": int(executed_bytes)},
+                     "kernel": "frame_warp_kernel<3,false,false> + frame_extent_kernel + frame_gradient_kernel<3> (the 3 launches "
+                               "of one isx_frame_blend call: warp, both bounding boxes, extents, feather blend in place)",
+                     "kernel_us": us, "timing": timing, "synchronous_call_us": sync_us, "algorithmic_bytes": int(alg_bytes), "executed_bytes": int(executed_bytes)},
     }
 
 

@@ -28,6 +28,7 @@
 //   resolved at the memory side, ~30 ns each, serialised per address (the first version spent 16 + 50 us there).
 #include "isx_common.h"
 #include "isx_image_dev.h"
+#include "isx_ctx.h"
 #include <string.h>
 
 // result block (int32)
@@ -43,51 +44,6 @@ enum {
 };
 #define FRAME_MAX_WAVES 16
 #define FE_BATCH 1536 // rows of bit mask staged in LDS at a time (48 KiB)
-
-struct isx_ctx {
-    int device;
-    uint8_t *wbuf;
-    size_t wbuf_cap;
-    int32_t *rows; // gradient: qh x int4 {GL, GR, L0, R0} (gray != 0 extent, channel-0 != 0 extent; canvas x)
-    size_t rows_cap;
-    int32_t *cols; // 2 x qw {top, bottom}
-    size_t cols_cap;
-    uint64_t *mask; // qh x nchunk x 4 ballots
-    size_t mask_cap;
-    int32_t *out_dev; // R_INTS result ints, then the table folded on the host
-    size_t out_cap;
-    int32_t *out_host; // pinned mirror of out_dev
-    size_t out_host_cap;
-    int pending;    // kernels queued whose results have not been read back: 1 = gradient, 2 = alpha
-    int fold_n;     // entries of the table behind the result block (gradient: workgroups of K3; alpha: rows of Q)
-    int fold_qy0;   // alpha: canvas y of the table's first row
-    int32_t last[R_INTS];
-};
-
-template <typename T>
-static int ctx_ensure(T **p, size_t *cap, size_t need) {
-    if (*cap >= need) return ISX_OK;
-    if (*p) ISX_HIP_TRY(hipFree(*p));
-    *p = nullptr;
-    *cap = 0;
-    const size_t want = need + need / 2;
-    ISX_HIP_TRY(hipMalloc((void **)p, want * sizeof(T)));
-    *cap = want;
-    return ISX_OK;
-}
-
-static int ctx_ensure_out(isx_ctx *c, size_t ints) {
-    int rc = ctx_ensure(&c->out_dev, &c->out_cap, ints);
-    if (rc != ISX_OK) return rc;
-    if (c->out_host_cap < c->out_cap) {
-        if (c->out_host) ISX_HIP_TRY(hipHostFree(c->out_host));
-        c->out_host = nullptr;
-        c->out_host_cap = 0;
-        ISX_HIP_TRY(hipHostMalloc((void **)&c->out_host, c->out_cap * 4, hipHostMallocDefault));
-        c->out_host_cap = c->out_cap;
-    }
-    return ISX_OK;
-}
 
 extern "C" int isx_ctx_create(isx_ctx **out) {
     ISX_REQUIRE(out, "null out");
@@ -115,6 +71,8 @@ extern "C" int isx_ctx_destroy(isx_ctx *c) {
     if (c->mask) (void)hipFree(c->mask);
     if (c->out_dev) (void)hipFree(c->out_dev);
     if (c->out_host) (void)hipHostFree(c->out_host);
+    if (c->hs_dev) (void)hipFree(c->hs_dev);
+    if (c->hs_host) (void)hipHostFree(c->hs_host);
     delete c;
     return ISX_OK;
 }

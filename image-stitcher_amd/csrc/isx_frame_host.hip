@@ -1,0 +1,205 @@
+// Composite, SYNCHRONOUS per-frame host calls on an isx_ctx: Stitcher.get_matches + filter_matches and
+// Stitcher.get_transform (reference stitcher.py:106-127, :135-141) each as ONE library call that stages its inputs
+// through the ctx's pinned block (one host-to-device copy), queues the kernels of the fine-grained entry points
+// (isx_desc_prep / isx_knn2_*_items / isx_ratio_compact, isx_ransac_*) and reads everything back with one or two
+// device-to-host copies.  Same kernels, same results as calling those entry points one by one; what goes away is
+// the per-call allocation, copy and synchronisation of the host layer (8 uploads and 11 read-backs per frame).
+#include "isx_ctx.h"
+#include <float.h>
+#include <string.h>
+
+static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// status_out values of isx_frame_match
+enum { FM_OK = 0, FM_NOT_INTEGER = 1, FM_NORM_LIMIT = 2 };
+
+extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const void *t_host, int nt, int d, int dtype,
+                               int norm, double ratio, int32_t *good_q_out_host, int32_t *good_t_out_host,
+                               int32_t *n_good_out, int32_t *status_out, void *stream) {
+    ISX_REQUIRE(ctx && q_host && t_host && good_q_out_host && good_t_out_host && n_good_out && status_out, "null argument");
+    ISX_REQUIRE(nq > 0 && nt > 0 && d > 0, "empty descriptor set");
+    ISX_REQUIRE(dtype == ISX_U8 || dtype == ISX_F32, "bad dtype %d", dtype);
+    ISX_REQUIRE(norm == ISX_NORM_L2 || (norm == ISX_NORM_HAMMING && dtype == ISX_U8), "Hamming needs uint8 descriptors");
+    ISX_REQUIRE(nt < (1 << 18), "cv2's own limit: train rows must be < 2^18");
+    int cur = -1;
+    ISX_HIP_TRY(hipGetDevice(&cur));
+    ISX_REQUIRE(cur == ctx->device, "ctx belongs to device %d but device %d is current", ctx->device, cur);
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = nq + nt;
+    int d_pad;
+    if (norm == ISX_NORM_HAMMING) {
+        ISX_REQUIRE(d <= 64, "Hamming descriptors of up to 64 bytes");
+        d_pad = d <= 32 ? 32 : 64;
+    } else {
+        d_pad = isx_desc_pad(d);
+        if (d_pad < 0) return d_pad;
+    }
+    const size_t elem = dtype == ISX_U8 ? 1 : 4;
+    // raw rows as uploaded: L2 keeps the caller's width (isx_desc_prep pads), Hamming is padded on the way in
+    const size_t raw_row = norm == ISX_NORM_HAMMING ? (size_t)d_pad : (size_t)d * elem;
+    // block layout (device and pinned mirror): [header 256][raw rows][-- device only below --]
+    //   header: isx_knn_item (16) | out_start int64 (8) | count int32 | stats int32[2] | compact count int32
+    const size_t o_raw = 256, o_desc = o_raw + up256(raw_row * rows), o_cbase = o_desc + up256((size_t)d_pad * rows);
+    const size_t o_nrm = o_cbase + up256(4 * (size_t)rows), o_cin = o_nrm + up256(4 * (size_t)rows);
+    const size_t o_idx = o_cin + up256(4 * (size_t)rows), o_dist = o_idx + up256(8 * (size_t)nq);
+    const size_t o_out = o_dist + up256(8 * (size_t)nq); // read-back region: [hdr copy 64][good_q nq][good_t nq]
+    const size_t o_gq = o_out + 64, o_gt = o_gq + 4 * (size_t)nq, total = o_gt + 4 * (size_t)nq + 256;
+    int rc = ctx_ensure_staging(ctx, total);
+    if (rc != ISX_OK) return rc;
+    uint8_t *H = ctx->hs_host, *D = ctx->hs_dev;
+    memset(H, 0, 256);
+    isx_knn_item *item = (isx_knn_item *)H;
+    item->q_start = 0, item->nq = nq, item->t_start = nq, item->nt = nt;
+    if (norm == ISX_NORM_HAMMING && d != d_pad) {
+        memset(H + o_raw, 0, raw_row * rows);
+        for (int r = 0; r < nq; r++) memcpy(H + o_raw + raw_row * r, (const uint8_t *)q_host + (size_t)d * r, d);
+        for (int r = 0; r < nt; r++) memcpy(H + o_raw + raw_row * (nq + r), (const uint8_t *)t_host + (size_t)d * r, d);
+    } else {
+        memcpy(H + o_raw, q_host, raw_row * nq);
+        memcpy(H + o_raw + raw_row * nq, t_host, raw_row * nt);
+    }
+    ISX_HIP_TRY(hipMemcpyAsync(D, H, o_raw + raw_row * rows, hipMemcpyHostToDevice, st));
+    const isx_knn_item *items_dev = (const isx_knn_item *)D;
+    const int64_t *out_start_dev = (const int64_t *)(D + 16);
+    int32_t *count_dev = (int32_t *)(D + 24), *stats_dev = (int32_t *)(D + 28), *ccount_dev = (int32_t *)(D + 36);
+    int32_t *idx_dev = (int32_t *)(D + o_idx);
+    float *dist_dev = (float *)(D + o_dist);
+    if (norm == ISX_NORM_HAMMING) {
+        rc = isx_knn2_hamming_items(D + o_raw, d_pad, items_dev, 1, nq, nt, ratio, idx_dev, dist_dev, out_start_dev, count_dev, st);
+    } else {
+        rc = isx_desc_prep(D + o_raw, dtype, rows, d, (int8_t *)(D + o_desc), (uint32_t *)(D + o_cbase), (int32_t *)(D + o_nrm),
+                           (int32_t *)(D + o_cin), stats_dev, st);
+        if (rc != ISX_OK) return rc;
+        rc = isx_knn2_l2_items((const int8_t *)(D + o_desc), (const uint32_t *)(D + o_cbase), (const int32_t *)(D + o_nrm), d_pad,
+                               items_dev, 1, nq, ratio, idx_dev, dist_dev, out_start_dev, count_dev, st);
+    }
+    if (rc != ISX_OK) return rc;
+    rc = isx_ratio_compact(idx_dev, dist_dev, nq, ratio, (int32_t *)(D + o_gq), (int32_t *)(D + o_gt), ccount_dev, st);
+    if (rc != ISX_OK) return rc;
+    // one read-back: header (counts, stats) + both index lists
+    ISX_HIP_TRY(hipMemcpyAsync(D + o_out, D, 64, hipMemcpyDeviceToDevice, st));
+    ISX_HIP_TRY(hipMemcpyAsync(H + o_out, D + o_out, 64 + 8 * (size_t)nq, hipMemcpyDeviceToHost, st));
+    ISX_HIP_TRY(hipStreamSynchronize(st));
+    const int32_t *hdr = (const int32_t *)(H + o_out);
+    const int32_t stats0 = hdr[7], stats1 = hdr[8], g = hdr[9];
+    *status_out = FM_OK;
+    *n_good_out = 0;
+    if (norm == ISX_NORM_L2) {
+        if (stats0 & 1) {
+            *status_out = FM_NOT_INTEGER;
+            return ISX_OK;
+        }
+        if (2 * (int64_t)stats1 >= ISX_L2_EXACT_LIMIT) {
+            *status_out = FM_NORM_LIMIT;
+            return ISX_OK;
+        }
+    }
+    ISX_REQUIRE(g >= 0 && g <= nq, "compaction count %d outside 0..%d", g, nq);
+    memcpy(good_q_out_host, H + o_gq, 4 * (size_t)g);
+    memcpy(good_t_out_host, H + o_gt, 4 * (size_t)g);
+    *n_good_out = g;
+    return ISX_OK;
+}
+
+extern "C" int isx_frame_transform(isx_ctx *ctx, const float *src_host, const float *dst_host, int n, int model,
+                                   double *M_out_host, uint8_t *mask_out_host, int32_t *found_out, void *stream) {
+    ISX_REQUIRE(ctx && M_out_host && found_out, "null argument");
+    ISX_REQUIRE(model == ISX_MODEL_AFFINE_PARTIAL || model == ISX_MODEL_HOMOGRAPHY, "bad model %d", model);
+    ISX_REQUIRE(n >= 0, "negative point count");
+    int cur = -1;
+    ISX_HIP_TRY(hipGetDevice(&cur));
+    ISX_REQUIRE(cur == ctx->device, "ctx belongs to device %d but device %d is current", ctx->device, cur);
+    hipStream_t st = (hipStream_t)stream;
+    const bool persp = model == ISX_MODEL_HOMOGRAPHY;
+    // cv2 defaults of the two calls the reference makes (stitcher.py:138, :140)
+    const double thr = persp ? 5.0 : 3.0, confidence = persp ? 0.995 : 0.99;
+    const int max_iters = 2000, refine_iters = 10, mp = persp ? 4 : 2, msz = persp ? 9 : 6;
+    *found_out = 0;
+    if (mask_out_host && n > 0) memset(mask_out_host, 0, n);
+    if (n < mp) return ISX_OK;
+    ISX_REQUIRE(src_host && dst_host, "null points");
+    // block: [src n*8][dst n*8][subsets max_iters*mp*4] (uploaded) | models | valid | counts | M | mask | info
+    const size_t o_src = 0, o_dst = up256(8 * (size_t)n), o_sub = o_dst + up256(8 * (size_t)n);
+    const size_t o_models = o_sub + up256(4 * (size_t)max_iters * mp), o_valid = o_models + up256(8 * (size_t)max_iters * msz);
+    const size_t o_counts = o_valid + up256(4 * (size_t)max_iters); // valid and counts are read back together
+    const size_t o_M = o_counts + up256(4 * (size_t)max_iters), o_info = o_M + 128, o_mask = o_info + 128;
+    const size_t total = o_mask + up256((size_t)n) + 256;
+    int rc = ctx_ensure_staging(ctx, total);
+    if (rc != ISX_OK) return rc;
+    uint8_t *H = ctx->hs_host, *D = ctx->hs_dev;
+    memcpy(H + o_src, src_host, 8 * (size_t)n);
+    memcpy(H + o_dst, dst_host, 8 * (size_t)n);
+    const int k = isx_ransac_sample(model, src_host, dst_host, n, max_iters, (int32_t *)(H + o_sub));
+    if (k < 0) return k;
+    if (k == 0) return ISX_OK;
+    ISX_HIP_TRY(hipMemcpyAsync(D, H, o_sub + 4 * (size_t)k * mp, hipMemcpyHostToDevice, st));
+    const float *sd = (const float *)(D + o_src), *dd = (const float *)(D + o_dst);
+    double *models = (double *)(D + o_models);
+    int32_t *valid = (int32_t *)(D + o_valid), *counts = (int32_t *)(D + o_counts);
+    rc = isx_ransac_hypotheses(model, sd, dd, n, (const int32_t *)(D + o_sub), k, models, valid, st);
+    if (rc != ISX_OK) return rc;
+    if (n == mp) { // cv: direct solve, mask of ones, no refinement
+        ISX_HIP_TRY(hipMemcpyAsync(H + o_models, models, 8 * (size_t)msz, hipMemcpyDeviceToHost, st));
+        ISX_HIP_TRY(hipMemcpyAsync(H + o_valid, valid, 4, hipMemcpyDeviceToHost, st));
+        ISX_HIP_TRY(hipStreamSynchronize(st));
+        if (!*(const int32_t *)(H + o_valid)) return ISX_OK;
+        memcpy(M_out_host, H + o_models, 8 * (size_t)msz);
+        if (mask_out_host) memset(mask_out_host, 1, n);
+        *found_out = 1;
+        return ISX_OK;
+    }
+    rc = isx_ransac_score(model, models, k, valid, sd, dd, n, thr, counts, st);
+    if (rc != ISX_OK) return rc;
+    ISX_HIP_TRY(hipMemcpyAsync(H + o_valid, valid, (o_counts - o_valid) + 4 * (size_t)k, hipMemcpyDeviceToHost, st));
+    ISX_HIP_TRY(hipStreamSynchronize(st));
+    int32_t best = -1, iters = 0;
+    rc = isx_ransac_select(model, (const int32_t *)(H + o_counts), (const int32_t *)(H + o_valid), k, n, confidence, max_iters,
+                           &best, &iters);
+    if (rc != ISX_OK) return rc;
+    if (best < 0) return ISX_OK;
+    double *M_dev = (double *)(D + o_M);
+    ISX_HIP_TRY(hipMemcpyAsync(M_dev, models + (size_t)best * msz, 8 * (size_t)msz, hipMemcpyDeviceToDevice, st));
+    rc = isx_ransac_refine(model, M_dev, sd, dd, n, thr, persp ? 1 : 0, refine_iters, D + o_mask, (int32_t *)(D + o_info), st);
+    if (rc != ISX_OK) return rc;
+    ISX_HIP_TRY(hipMemcpyAsync(H + o_M, D + o_M, (o_mask - o_M) + (size_t)n, hipMemcpyDeviceToHost, st));
+    ISX_HIP_TRY(hipStreamSynchronize(st));
+    memcpy(M_out_host, H + o_M, 8 * (size_t)msz);
+    if (mask_out_host) memcpy(mask_out_host, H + o_mask, n);
+    *found_out = 1;
+    return ISX_OK;
+}
+
+// Pitched device-to-host download of a sub-rectangle into the ctx's pinned block (SYNCHRONOUS): the region of the
+// resident mosaic the CPU detector is run on (Stitcher.detectAndComputeFromCorners, reference stitcher.py:159-165
+// slices the padded canvas there).  The block is laid out as out_h rows of out_row_bytes; the h x row_bytes source
+// rectangle lands at row off_y, byte off_x of it and everything around it is zeroed (the canvas's padding).
+// *host_out points into the ctx and stays valid until the next call on this ctx that stages data
+// (isx_frame_match / isx_frame_transform / isx_frame_download).
+extern "C" int isx_frame_download(isx_ctx *ctx, const uint8_t *src_dev, int64_t spitch, int h, int64_t row_bytes, int out_h,
+                                  int64_t out_row_bytes, int off_y, int64_t off_x, const uint8_t **host_out, void *stream) {
+    ISX_REQUIRE(ctx && host_out, "null argument");
+    ISX_REQUIRE(h >= 0 && row_bytes >= 0 && out_h >= 0 && out_row_bytes >= 0 && off_y >= 0 && off_x >= 0 &&
+                    off_y + h <= out_h && off_x + row_bytes <= out_row_bytes,
+                "source rectangle does not fit the output block");
+    const size_t bytes = (size_t)out_h * (size_t)out_row_bytes;
+    int rc = ctx_ensure_staging(ctx, bytes + 256);
+    if (rc != ISX_OK) return rc;
+    uint8_t *H = ctx->hs_host;
+    *host_out = H;
+    if (bytes == 0) return ISX_OK;
+    const bool copy = h > 0 && row_bytes > 0;
+    ISX_REQUIRE(!copy || (src_dev && spitch >= row_bytes), "bad download arguments");
+    // Assemble the block on the device (zero fill + pitched device-to-device copy: both are kernels), then ONE
+    // contiguous DMA to the pinned mirror.  A pitched device-to-HOST copy whose two pitches differ is executed row by
+    // row by the runtime (measured: 4.7 ms for 1180 rows against 0.15 ms this way).
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t *D = ctx->hs_dev;
+    const bool whole = copy && h == out_h && row_bytes == out_row_bytes;
+    if (!whole) ISX_HIP_TRY(hipMemsetAsync(D, 0, bytes, st));
+    if (copy)
+        ISX_HIP_TRY(hipMemcpy2DAsync(D + (size_t)off_y * out_row_bytes + off_x, (size_t)out_row_bytes, src_dev, (size_t)spitch,
+                                     (size_t)row_bytes, (size_t)h, hipMemcpyDeviceToDevice, st));
+    ISX_HIP_TRY(hipMemcpyAsync(H, D, bytes, hipMemcpyDeviceToHost, st));
+    ISX_HIP_TRY(hipStreamSynchronize(st));
+    return ISX_OK;
+}

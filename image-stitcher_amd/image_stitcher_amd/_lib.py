@@ -52,11 +52,16 @@ SIGNATURES = {
                                 c_double, c_void_p]),
     "isx_gradient_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
                                    c_void_p]),
+    "isx_frame_download": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_void_p,
+                                   c_void_p]),
     "isx_ctx_create": (c_int, [c_void_p]),
     "isx_ctx_destroy": (c_int, [c_void_p]),
     "isx_frame_blend": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_int,
                                 c_int, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_double,
                                 c_int, c_void_p, c_void_p]),
+    "isx_frame_match": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
+    "isx_frame_transform": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "isx_frame_result": (c_int, [c_void_p, c_void_p, c_void_p]),
     "isx_frame_warped": (c_int, [c_void_p, c_void_p]),
     "isx_copy2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_void_p]),

@@ -21,6 +21,16 @@ class KeyPoint:
         self.response = response
 
 
+class KeyPointList(list):
+    """list of KeyPoint objects that also keeps the coordinates as an (n,2) float32 array (`xy`), so that the
+    stitcher does not have to walk the objects (cv2 offers cv2.KeyPoint_convert for the same purpose)."""
+    __slots__ = ("xy",)
+
+    def __init__(self, kps, xy):
+        super().__init__(kps)
+        self.xy = xy
+
+
 def make_detector(algorithm):
     try:
         import cv2
@@ -89,7 +99,7 @@ class NumpyOrbLite:
         a = g[ys[:, None] + p[None, :, 1], xs[:, None] + p[None, :, 0]]
         b = g[ys[:, None] + p[None, :, 3], xs[:, None] + p[None, :, 2]]
         des = np.packbits(a < b, axis=1)
-        kps = [KeyPoint(x, y, v) for x, y, v in zip(xs, ys, resp)]
+        kps = KeyPointList([KeyPoint(x, y, v) for x, y, v in zip(xs, ys, resp)], np.stack([xs, ys], 1).astype(np.float32))
         return kps, des
 
 
@@ -121,5 +131,5 @@ class NumpySiftLite(NumpyOrbLite):
         np.minimum(hist, 0.2, out=hist)
         hist /= np.maximum(np.linalg.norm(hist, axis=1, keepdims=True), 1e-12)
         des = np.clip(np.rint(hist * 512.0), 0, 255).astype(np.float32)
-        kps = [KeyPoint(x, y, v) for x, y, v in zip(xs, ys, resp)]
+        kps = KeyPointList([KeyPoint(x, y, v) for x, y, v in zip(xs, ys, resp)], np.stack([xs, ys], 1).astype(np.float32))
         return kps, des

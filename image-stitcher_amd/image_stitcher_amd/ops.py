@@ -504,6 +504,25 @@ def gradient_blend_roi(warped_roi, ref_roi, feather=10, ext=None):
     return ref_roi
 
 
+def frame_download(ctx, img, out_hw=None, offset=(0, 0)):
+    """uint8 device image (possibly a strided view) -> numpy VIEW of the ctx's pinned block holding a contiguous copy
+    (one pitched DMA).  out_hw = (H, W) and offset = (y, x): the copy is placed at that position of a zero-filled H x W
+    image (a slice of the reference's padded canvas that reaches beyond the mosaic).  Valid until the next
+    frame_match / frame_transform / frame_download on this ctx."""
+    p, h, w, c, pitch = _img_args(img)
+    oh, ow = (h, w) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
+    shape = (oh, ow) + tuple(img.shape[2:])
+    out = ctypes.c_void_p()
+    with torch.cuda.device(img.device):
+        check(_lib.lib().isx_frame_download(ctx._h, p, pitch, h, w * c, oh, ow * c, int(offset[0]), int(offset[1]) * c,
+                                            ctypes.byref(out), _stream()))
+    n = oh * ow * c
+    if n == 0:
+        return np.zeros(shape, np.uint8)
+    buf = (ctypes.c_uint8 * n).from_address(out.value)
+    return np.frombuffer(buf, np.uint8).reshape(shape)
+
+
 class FrameCtx:
     """isx_ctx (include/isx.h): the per-device workspace of the per-frame pipeline."""
 
@@ -524,12 +543,74 @@ class FrameCtx:
                 pass
 
 
+def frame_match(ctx, q, t, ratio, hamming=False):
+    """isx_frame_match: cv2.BFMatcher(L2 | HAMMING).knnMatch(q, t, k=2) + the Lowe ratio loop for one pair in ONE
+    synchronous library call.  q, t: (n, d) numpy uint8 / float32 (integer valued).  Returns (good_q, good_t)
+    int32 numpy arrays in query order; raises NotIntegerValuedError / NormLimitError like prepare_descriptors."""
+    q = np.ascontiguousarray(q)
+    t = np.ascontiguousarray(t)
+    if q.ndim != 2 or t.ndim != 2 or q.shape[1] != t.shape[1] or q.dtype != t.dtype:
+        raise IsxError("descriptor arrays must be 2-D and share width and dtype")
+    if q.dtype not in (np.uint8, np.float32):
+        raise IsxError(f"descriptor dtype must be uint8 or float32 (got {q.dtype})")
+    nq, nt, d = q.shape[0], t.shape[0], q.shape[1]
+    gq = np.empty((nq,), np.int32)
+    gt = np.empty((nq,), np.int32)
+    n_good, status = ctypes.c_int32(0), ctypes.c_int32(0)
+    with torch.cuda.device(ctx.device):
+        check(_lib.lib().isx_frame_match(ctx._h, q.ctypes.data_as(ctypes.c_void_p), nq, t.ctypes.data_as(ctypes.c_void_p), nt, d,
+                                         _lib.U8 if q.dtype == np.uint8 else _lib.F32,
+                                         _lib.NORM_HAMMING if hamming else _lib.NORM_L2, float(ratio),
+                                         gq.ctypes.data_as(ctypes.c_void_p), gt.ctypes.data_as(ctypes.c_void_p),
+                                         ctypes.byref(n_good), ctypes.byref(status), _stream()))
+    if status.value == 1:
+        raise NotIntegerValuedError("float descriptors are not integer valued in [0,255]")
+    if status.value == 2:
+        raise NormLimitError("descriptor norms too large for the exact integer path")
+    return gq[:n_good.value], gt[:n_good.value]
+
+
+def frame_transform(ctx, src_pts, dst_pts, perspective):
+    """isx_frame_transform: cv2.estimateAffinePartial2D / cv2.findHomography(RANSAC, 5.0) in ONE synchronous library
+    call.  Returns (M float64 (2,3)|(3,3) or None, mask uint8 (n,1)) like estimate_transform."""
+    s = np.ascontiguousarray(np.asarray(src_pts, np.float32).reshape(-1, 2))
+    d = np.ascontiguousarray(np.asarray(dst_pts, np.float32).reshape(-1, 2))
+    n = len(s)
+    if len(d) != n:
+        raise IsxError("src_pts and dst_pts differ in length")
+    M = np.zeros((9,), np.float64)
+    mask = np.zeros((max(n, 1),), np.uint8)
+    found = ctypes.c_int32(0)
+    with torch.cuda.device(ctx.device):
+        check(_lib.lib().isx_frame_transform(ctx._h, s.ctypes.data_as(ctypes.c_void_p), d.ctypes.data_as(ctypes.c_void_p), n,
+                                             _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL,
+                                             M.ctypes.data_as(ctypes.c_void_p), mask.ctypes.data_as(ctypes.c_void_p),
+                                             ctypes.byref(found), _stream()))
+    if not found.value:
+        return None, np.zeros((n, 1), np.uint8)
+    return (M.reshape(3, 3) if perspective else M[:6].reshape(2, 3)).copy(), mask[:n].reshape(-1, 1)
+
+
+def _frame_result_dict(r):
+    v = r.tolist()
+    return {"wbbox": tuple(v[0:4]) if v[4] else False, "roi": tuple(v[5:9]), "mbbox": tuple(v[9:13]), "mfound": bool(v[13]),
+            "zeroed": v[14], "dirty": v[15], "rows_ok": bool(v[16]), "done": bool(v[17])}
+
+
+def frame_result(ctx):
+    """Result block of the last frame_blend(..., fetch=False) on this ctx (synchronises the current stream)."""
+    r = ctx._res
+    with torch.cuda.device(ctx.device):
+        check(_lib.lib().isx_frame_result(ctx._h, r.ctypes.data_as(ctypes.c_void_p), _stream()))
+    return _frame_result_dict(r)
+
+
 def frame_blend(ctx, src, M, perspective, src_xy, canvas_wh, arena_t, canvas_to_arena, q_rect, blender,
-                contrib=0.5, feather=10, arith="f32"):
+                contrib=0.5, feather=10, arith="f32", fetch=True):
     """isx_frame_blend: warp `src` (pasted at src_xy of the virtual canvas) by M and blend it IN PLACE into the
     mosaic held by arena_t (canvas (X, Y) is arena pixel (X + canvas_to_arena[0], Y + canvas_to_arena[1])), only over
     the canvas rectangle q_rect = (x0, y0, w, h).  Synchronous; returns the int32 result block as a dict of python
-    ints / tuples."""
+    ints / tuples.  fetch=False only queues the kernels (returns None; frame_result() reads the block later)."""
     p, sh, sw, c, spitch = _img_args(src, "src")
     pa, ah, aw, ac, apitch = _img_args(arena_t, "arena")
     if ac != c:
@@ -549,10 +630,8 @@ def frame_blend(ctx, src, M, perspective, src_xy, canvas_wh, arena_t, canvas_to_
                                          _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL,
                                          WARP_ARITH[arith], int(canvas_wh[0]), int(canvas_wh[1]), mq, apitch, qx0, qy0, qw, qh,
                                          int(blender), float(contrib), int(feather),
-                                         r.ctypes.data_as(ctypes.c_void_p), _stream()))
-    v = r.tolist()
-    return {"wbbox": tuple(v[0:4]) if v[4] else False, "roi": tuple(v[5:9]), "mbbox": tuple(v[9:13]), "mfound": bool(v[13]),
-            "zeroed": v[14], "dirty": v[15], "rows_ok": bool(v[16]), "done": bool(v[17])}
+                                         r.ctypes.data_as(ctypes.c_void_p) if fetch else None, _stream()))
+    return _frame_result_dict(r) if fetch else None
 
 
 def frame_warped_view(ctx, q_rect, c, ndim3):

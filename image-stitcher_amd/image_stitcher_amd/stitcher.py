@@ -19,6 +19,7 @@ Deliberate differences from the reference:
 import copy
 import logging
 import os
+import time
 
 import numpy as np
 import torch
@@ -94,7 +95,21 @@ def _kp_array(kps):
     """keypoints (cv2.KeyPoint-like objects or an (n,2) array) -> (n,2) float32"""
     if isinstance(kps, np.ndarray):
         return kps.astype(np.float32, copy=False).reshape(-1, 2)
+    xy = getattr(kps, "xy", None)  # detect.KeyPointList: coordinates kept as an array beside the objects
+    if xy is not None and len(xy) == len(kps):
+        return np.asarray(xy, np.float32).reshape(-1, 2)
+    if len(kps) and type(kps[0]).__module__.startswith("cv2"):
+        import cv2
+        return np.asarray(cv2.KeyPoint_convert(kps), np.float32).reshape(-1, 2)
     return np.array([kp.pt for kp in kps], dtype=np.float32).reshape(-1, 2)
+
+
+def _kp_shifted(kps, origin):
+    """transform_keypoints_from_roi (utils/proc.py:315-322) on coordinates only: (n,2) float32 of kp.pt + origin,
+    summed in float64 as the reference's Python floats are and rounded once, as np.float32([...]) does in get_pts."""
+    xy = _kp_array(kps).astype(np.float64)
+    xy += np.asarray(origin, np.float64)
+    return xy.astype(np.float32)
 
 
 class Stitcher:
@@ -174,6 +189,8 @@ class Stitcher:
         self._pool = None
         self._writer = None
         self._ctx = None          # ops.FrameCtx, created on first use
+        self._seams_plain_cache = None
+        self.phase_seconds = {}   # diagnostics: wall seconds per phase of `stitch`
         self._inplace_ok = False  # set by the internal callers that replace the reference mosaic by the result
         self.frame_stats = {"frames": 0, "rows_slow": 0, "rescans": 0, "clears": 0, "arena_allocs": 0}  # diagnostics
 
@@ -340,8 +357,7 @@ class Stitcher:
         out[oy:oy + img_host.shape[0], ox:ox + img_host.shape[1]] = img_host
         return out
 
-    @staticmethod
-    def _host_region(img, ox, oy, H, W, p1, p2):
+    def _host_region(self, img, ox, oy, H, W, p1, p2):
         """get_roi_from_corners on the padded canvas of `img` (pasted at ox, oy) without building the
         canvas: numpy slice semantics (clipped to the canvas), zeros outside the image."""
         if isinstance(img, DeviceImage) and img._host is not None:
@@ -351,12 +367,21 @@ class Stitcher:
         if x0 >= ox and y0 >= oy and x1 <= ox + img.shape[1] and y1 <= oy + img.shape[0] and x1 > x0 and y1 > y0:
             # the region lies inside the image (the usual case): a view of the host frame / a download of
             # just that part of the resident mosaic -- no zero canvas, no second copy
+            if isinstance(img, DeviceImage) and self._seams_plain:
+                # one pitched DMA into the ctx's pinned block; the view is consumed by the detector right away
+                # (before the next staging call on the ctx)
+                return ops.frame_download(self._frame_ctx(), img.t[y0 - oy:y1 - oy, x0 - ox:x1 - ox])
             return np.asarray(img[y0 - oy:y1 - oy, x0 - ox:x1 - ox])
-        c = () if img.ndim == 2 else (img.shape[2],)
-        out = np.zeros((y1 - y0, x1 - x0) + c, np.uint8)
         ix0, iy0 = max(x0, ox), max(y0, oy)
         ix1, iy1 = min(x1, ox + img.shape[1]), min(y1, oy + img.shape[0])
-        if ix1 > ix0 and iy1 > iy0:
+        inter = ix1 > ix0 and iy1 > iy0
+        if isinstance(img, DeviceImage) and self._seams_plain and x1 > x0 and y1 > y0:
+            # the slice reaches beyond the mosaic: zero frame + one pitched DMA of the part that exists, in the ctx
+            src = img.t[iy0 - oy:iy1 - oy, ix0 - ox:ix1 - ox] if inter else img.t[0:0, 0:0]
+            return ops.frame_download(self._frame_ctx(), src, (y1 - y0, x1 - x0), (iy0 - y0, ix0 - x0) if inter else (0, 0))
+        c = () if img.ndim == 2 else (img.shape[2],)
+        out = np.zeros((y1 - y0, x1 - x0) + c, np.uint8)
+        if inter:
             src = img[iy0 - oy:iy1 - oy, ix0 - ox:ix1 - ox]
             out[iy0 - y0:iy1 - y0, ix0 - x0:ix1 - x0] = np.asarray(src)
         return out
@@ -376,6 +401,30 @@ class Stitcher:
         x1 = int(np.ceil(xy[:, 0].max())) + 3 + margin
         y1 = int(np.ceil(xy[:, 1].max())) + 3 + margin
         return max(0, x0), max(0, y0), min(W, x1), min(H, y1)
+
+    @property
+    def _seams_plain(self):
+        """True when no subclass replaced a matching / transform seam (stitcher.py:106-141): `stitch` then runs them as
+        two composite library calls (ops.frame_match, ops.frame_transform) -- same kernels, same results."""
+        v = self._seams_plain_cache
+        if v is None:
+            v = not any(self._overridden(n) for n in ("get_matches", "filter_matches", "get_pts", "get_transform"))
+            self._seams_plain_cache = v
+        return v
+
+    def _good_matches_fast(self, des1, des2):
+        """get_matches + filter_matches (stitcher.py:106-127) for one pair in one library call."""
+        if des1 is None or des2 is None or len(des1) == 0 or len(des2) == 0:
+            return GoodMatches(np.zeros(0, np.int32), np.zeros(0, np.int32))
+        kind = self._route(des1)
+        if kind != "f32":
+            try:
+                with torch.cuda.device(self._dev()):
+                    gq, gt = ops.frame_match(self._frame_ctx(), des1, des2, self.lowes_ratio_threshold, hamming=(kind == "hamming"))
+                return GoodMatches(gq, gt)
+            except (ops.NormLimitError, ops.NotIntegerValuedError):
+                pass  # the float32 matcher computes what cv2 does for such descriptors (see get_matches)
+        return self.filter_matches(self.get_matches(des1, des2, 2))
 
     def _frame_ctx(self):
         if self._ctx is None:
@@ -486,8 +535,15 @@ class Stitcher:
             reference_image = np.ascontiguousarray(np.asarray(reference_image))
         return reference_image, corners, tf
 
+    def _phase(self, name, t0):
+        """Accumulate wall seconds per phase of `stitch` (diagnostics: bench.py reports them)."""
+        t1 = time.perf_counter()
+        self.phase_seconds[name] = self.phase_seconds.get(name, 0.0) + (t1 - t0)
+        return t1
+
     @timer
     def stitch(self, arg_ref, arg_img, tf=None, corners=None):
+        tp = time.perf_counter()
         dev = self._dev()
         img_d = DeviceImage.from_any(arg_img, dev)
         ref_d = DeviceImage.from_any(arg_ref, dev)
@@ -508,6 +564,7 @@ class Stitcher:
             current_corners = False
             self.logger.warning("Could not get image corners. The input image has no non-black regions.")
             corners = None
+        tp = self._phase("upload+frame_bbox", tp)
 
         if tf is None:
             thisdes = None
@@ -522,8 +579,12 @@ class Stitcher:
                         cur_roi = self._host_region(img_d, ox, oy, H, W, current_corners[0], current_corners[1])
                         (kps, thisdes), (rkps, refdes) = self._detect_two(
                             cur_roi, lambda: self._host_region(ref_d, rox, roy, H, W, corners[0], corners[1]))
-                        thiskp = transform_keypoints_from_roi(kps, current_corners[0])
-                        refkp = transform_keypoints_from_roi(rkps, corners[0])
+                        if self._seams_plain:
+                            # coordinates only (the keypoint objects do not leave this call): no per-object loops
+                            thiskp, refkp = _kp_shifted(kps, current_corners[0]), _kp_shifted(rkps, corners[0])
+                        else:
+                            thiskp = transform_keypoints_from_roi(kps, current_corners[0])
+                            refkp = transform_keypoints_from_roi(rkps, corners[0])
                 except Exception as e:  # same recovery as stitcher.py:189-191
                     self.logger.warning("Error in detecting keypoints from corners. Computing on whole image. Exception: ", str(e))
                     corners = None
@@ -531,17 +592,28 @@ class Stitcher:
                 (thiskp, thisdes), (refkp, refdes) = self._detect_two(
                     self._host_canvas(img_d.numpy(), H, W, ox, oy), lambda: self._host_canvas(ref_d.numpy(), H, W, rox, roy))
 
+            tp = self._phase("detect(cpu)+roi_download+kp", tp)
             if refdes is None:
                 self.logger.warning("Key points not found in ref. Moving to next blend.")
                 return False
 
-            matches = self.get_matches(thisdes, refdes, 2)
-            good_matches = self.filter_matches(matches)
+            if self._seams_plain:
+                good_matches = self._good_matches_fast(thisdes, refdes)
+            else:
+                matches = self.get_matches(thisdes, refdes, 2)
+                good_matches = self.filter_matches(matches)
+            tp = self._phase("match", tp)
             if len(good_matches) >= self.min_match_count:
                 self.logger.debug("Enough matches - {}/{}".format(len(good_matches), self.min_match_count))
                 src_pts, dst_pts = self.get_pts(thiskp, refkp, good_matches)
-                M = self.get_transform(src_pts, dst_pts)
+                tp = self._phase("get_pts", tp)
+                if self._seams_plain:
+                    with torch.cuda.device(dev):
+                        M, _mask = ops.frame_transform(self._frame_ctx(), src_pts, dst_pts, self.type == 1)
+                else:
+                    M = self.get_transform(src_pts, dst_pts)
                 tf = TransformDetails(M, src_pts, dst_pts)
+                tp = self._phase("transform", tp)
             else:
                 self.logger.debug("Cannot blend. Not enough matches found - {}/{}".format(len(good_matches), self.min_match_count))
                 return None
@@ -556,6 +628,7 @@ class Stitcher:
 
         with torch.cuda.device(dev):
             mosaic, wcorners = self._blend_resident(img_d, ref_d, M, W, H, rox, roy, ox, oy)
+        tp = self._phase("warp+blend", tp)
 
         if self.consecutive_range is not None:
             corners = wcorners

@@ -263,6 +263,32 @@ int isx_frame_result(isx_ctx *ctx, int32_t *result_host, void *stream);
 /* Device address of the warped image staged by the last gradient-path isx_frame_blend (Q-sized, pitch q_w * c). */
 int isx_frame_warped(isx_ctx *ctx, const uint8_t **wbuf_dev_out);
 
+/* Composite, SYNCHRONOUS forms of the matcher and of the robust transform for the per-frame path: each stages its
+ * host inputs through the ctx (one upload), queues the same kernels as the fine-grained entry points below /
+ * above and reads the results back in one or two copies.  Same results as calling those one by one.
+ *
+ * isx_frame_match = Stitcher.get_matches + Stitcher.filter_matches (stitcher.py:106-127) for one pair:
+ *   q_host / t_host : nq x d and nt x d descriptors, uint8 or float32 (ISX_NORM_L2: the exact integer path, as
+ *                     isx_desc_prep + isx_knn2_l2_items + isx_ratio_compact; ISX_NORM_HAMMING: uint8 only)
+ *   good_q/good_t_out_host : capacity nq int32 each; *n_good_out = len(good_matches), query order
+ *   *status_out : 0 ok; 1 = float descriptors are not integer valued in [0,255]; 2 = 2*max||v||^2 reaches
+ *                 ISX_L2_EXACT_LIMIT -- in both cases nothing is returned and the caller uses isx_knn2_f32_items */
+int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const void *t_host, int nt, int d, int dtype, int norm,
+                    double ratio, int32_t *good_q_out_host, int32_t *good_t_out_host, int32_t *n_good_out,
+                    int32_t *status_out, void *stream);
+/* isx_frame_transform = Stitcher.get_transform (stitcher.py:135-141) with cv2's defaults: sample (host) ->
+ * hypotheses -> score -> select (host) -> refine.  M_out_host: 6 (2x3) or 9 (3x3) doubles; mask_out_host: optional
+ * n uint8 inlier mask; *found_out = 0 <=> cv2 returns None. */
+int isx_frame_transform(isx_ctx *ctx, const float *src_host, const float *dst_host, int n, int model, double *M_out_host,
+                        uint8_t *mask_out_host, int32_t *found_out, void *stream);
+/* Pitched device-to-host download of a sub-rectangle into the ctx's pinned block, SYNCHRONOUS: the region of the
+ * resident mosaic the CPU detector is run on (Stitcher.detectAndComputeFromCorners, stitcher.py:159-165 slices the
+ * padded canvas there).  The block is out_h rows of out_row_bytes; the h x row_bytes source rectangle lands at row
+ * off_y, byte off_x and the rest is zero (the canvas's padding).  *host_out stays valid until the next staging call
+ * on this ctx. */
+int isx_frame_download(isx_ctx *ctx, const uint8_t *src_dev, int64_t spitch, int h, int64_t row_bytes, int out_h,
+                       int64_t out_row_bytes, int off_y, int64_t off_x, const uint8_t **host_out, void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Robust transform.  Replaces Stitcher.get_transform (stitcher.py:135-141):
  *   type 0: cv2.estimateAffinePartial2D(src, dst)       (RANSAC thr 3.0, 2000 iters, conf 0.99, 10 LM iters)
