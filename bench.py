@@ -277,21 +277,36 @@ def main():
     my_pairs = prs.shard_pairs(all_pairs, rank, world)
     plan = ops.plan_items(prs.directed_items(my_pairs, starts, counts), dev)
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    kernel_ms = []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]  # step start | after all_gather | after kernel | after gather
+    kernel_ms, parts = [], []
     result = {}
 
     def step(record):
+        if record:
+            marks[0].record()
         full = prs.all_gather_descriptors(local) if world > 1 else local
+        if record:
+            marks[1].record()
         P = ops.prepare_descriptor_tensor(full.reshape(-1, d), starts, counts)
         c = ops.knn2_l2_items(P, None, ratio, plan=plan, events=ev if record else None)
+        if record:
+            marks[2].record()
         allc = prs.gather_counts(c.view(-1, 2), len(all_pairs), rank, world)
+        if record:
+            marks[3].record()
+        t_host = time.perf_counter()
         if rank == 0:
             h = allc.cpu().numpy()
             comps, _ = prs.components_from_counts(n, all_pairs, h[:, 0], h[:, 1], min_match)
             result["comps"] = comps
         if record:
             torch.cuda.synchronize()
+            host_ms = (time.perf_counter() - t_host) * 1e3
             kernel_ms.append(ev[0].elapsed_time(ev[1]))
+            # per-phase GPU time of this rank's step: all_gather | desc_prep + count kernel | gather; host = counts
+            # read-back + union-find (rank 0)
+            parts.append((marks[0].elapsed_time(marks[1]), marks[1].elapsed_time(marks[2]), marks[2].elapsed_time(marks[3]),
+                          host_ms))
 
     def fence():
         torch.cuda.synchronize()
@@ -314,6 +329,21 @@ def main():
     # kernel-only duration for the roofline: separate, event-bracketed launches (not in the timed loop)
     for _ in range(3):
         step(True)
+    # attribution of a step over the ranks (so that a scaling-efficiency figure can be explained): every rank's mean
+    # all_gather / kernel / gather / host milliseconds, max and min over the ranks
+    mine = torch.tensor([float(np.mean(kernel_ms))] + [float(v) for v in np.mean(np.array(parts), 0)], dtype=torch.float64, device=dev)
+    if world > 1:
+        hi, lo = mine.clone(), mine.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    else:
+        hi = lo = mine
+    hi, lo = hi.cpu().numpy(), lo.cpu().numpy()
+    breakdown = {"kernel_ms": {"max": hi[0], "min": lo[0]}, "allgather_ms": {"max": hi[1], "min": lo[1]},
+                 "prep_plus_kernel_ms": {"max": hi[2], "min": lo[2]}, "gather_ms": {"max": hi[3], "min": lo[3]},
+                 "host_ms_rank0": float(np.mean(np.array(parts), 0)[3]),
+                 "note": "per rank: HIP events around each phase of 3 instrumented steps after the timed loop; host = counts "
+                         "read-back + union-find on rank 0"}
 
     if rank == 0:
         comps = result["comps"]
@@ -348,6 +378,7 @@ def main():
                          "kernel": "knn2_count16_kernel", "kernel_ms": k_ms,
                          "note": "int8 MFMA ops; algorithmic 2*Nq*Nt*D per unordered pair (the kernel executes 2x: one pass per direction)"},
         }
+        line["step_breakdown"] = breakdown
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(des, all_pairs, ratio, args.cpu_seconds)
         if world == 1 and not args.no_stitch:

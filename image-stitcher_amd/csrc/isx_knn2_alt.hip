@@ -114,6 +114,118 @@ extern "C" int isx_knn2_hamming_items(const uint8_t *desc_dev, int d_pad, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Exact L2 kNN-2 for byte descriptors of ANY norm (saturated AKAZE / ORB rows, dense synthetic bytes).  The MFMA
+// kernels rank on the integer squared distance s, which orders like cv2's float distances only while sqrtf is
+// injective on the integers in range (ISX_L2_EXACT_LIMIT).  Beyond it two different s can round to the SAME
+// float32 distance, and cv2 -- which compares the float distances, `d < best[K-1]` strictly, in train order --
+// then keeps the LOWER train index, whatever the integers were.  This kernel ranks on what cv2 compares: the
+// key is  bits(sqrtf((float)s)) << 20 | j  (positive floats order like their bit patterns; s < 2^24 is exact in
+// float32 and sqrtf is correctly rounded), so equal float distances resolve to the lowest index in both slots.
+// One lane owns one query (its int8 row stays in registers), train rows stream through LDS as wave-wide
+// broadcasts, a.b on v_dot4_i32_i8.  VALU-bound (no MFMA): a fallback for rare sets, ~10x the MFMA kernel's time.
+// ------------------------------------------------------------------------------------------------
+template <int W> // W = 32-bit words of a prepared row (8 / 16 / 32 for d_pad 32 / 64 / 128)
+__global__ void __launch_bounds__(256)
+knn2_l2_wide_kernel(const int32_t *__restrict__ desc, const int32_t *__restrict__ nrm, const isx_knn_item *__restrict__ items,
+                    int n_items, int nqb, double ratio, int32_t *__restrict__ idx_out, float *__restrict__ dist_out,
+                    const int64_t *__restrict__ out_start, int32_t *__restrict__ count_out) {
+    constexpr int CHUNK = 128;
+    __shared__ __align__(16) int32_t sm[CHUNK * W];
+    __shared__ int32_t sn[CHUNK];
+    const int item_i = blockIdx.x / nqb, qb = blockIdx.x % nqb;
+    if (item_i >= n_items) return;
+    const isx_knn_item it = items[item_i];
+    if (qb * 256 >= it.nq) return; // uniform per block
+    const int tid = threadIdx.x;
+    const int qi = qb * 256 + tid;
+    const bool live = qi < it.nq;
+    int32_t q[W];
+    {
+        const v4i *p = (const v4i *)(desc + (int64_t)(it.q_start + (live ? qi : 0)) * W);
+#pragma unroll
+        for (int u = 0; u < W / 4; u++) {
+            const v4i v = p[u];
+            q[4 * u] = v[0], q[4 * u + 1] = v[1], q[4 * u + 2] = v[2], q[4 * u + 3] = v[3];
+        }
+    }
+    const int na = nrm[it.q_start + (live ? qi : 0)];
+    uint64_t m1 = ~0ull, m2 = ~0ull;
+    for (int c0 = 0; c0 < it.nt; c0 += CHUNK) {
+        const int rows = min(CHUNK, it.nt - c0);
+        __syncthreads();
+        for (int u = tid; u < rows * (W / 4); u += 256)
+            ((v4i *)sm)[u] = ((const v4i *)(desc + (int64_t)(it.t_start + c0) * W))[u];
+        if (tid < rows) sn[tid] = nrm[it.t_start + c0 + tid];
+        __syncthreads();
+        for (int r = 0; r < rows; r++) {
+            const v4i *tp = (const v4i *)(sm + r * W); // same address on every lane: LDS broadcast
+            int dot = 0;
+#pragma unroll
+            for (int u = 0; u < W / 4; u++) {
+                const v4i t = tp[u];
+                dot = __builtin_amdgcn_sdot4(q[4 * u], t[0], dot, false);
+                dot = __builtin_amdgcn_sdot4(q[4 * u + 1], t[1], dot, false);
+                dot = __builtin_amdgcn_sdot4(q[4 * u + 2], t[2], dot, false);
+                dot = __builtin_amdgcn_sdot4(q[4 * u + 3], t[3], dot, false);
+            }
+            const int sq = na + sn[r] - 2 * dot; // exact ||a - b||^2 (the common -128 offset cancels)
+            const uint64_t key = ((uint64_t)__float_as_uint(sqrtf((float)sq)) << 20) | (uint64_t)(c0 + r);
+            const uint64_t lo = m1 < key ? m1 : key, hi = m1 < key ? key : m1;
+            m2 = hi < m2 ? hi : m2; // second smallest of {m1, m2, key}
+            m1 = lo;
+        }
+    }
+    bool good = false;
+    if (live) {
+        const bool has0 = m1 != ~0ull, has1 = m2 != ~0ull;
+        const float d0 = has0 ? __uint_as_float((uint32_t)(m1 >> 20)) : FLT_MAX, d1 = has1 ? __uint_as_float((uint32_t)(m2 >> 20)) : FLT_MAX;
+        good = has0 && (!has1 || (double)d0 < ratio * (double)d1);
+        if (idx_out) {
+            const int64_t o = (out_start[item_i] + qi) * 2;
+            idx_out[o] = has0 ? (int)(m1 & 0xFFFFFu) : -1;
+            idx_out[o + 1] = has1 ? (int)(m2 & 0xFFFFFu) : -1;
+            dist_out[o] = d0;
+            dist_out[o + 1] = d1;
+        }
+    }
+    const int cnt = __popcll(__ballot(good));
+    if (count_out && (tid & 63) == 0 && cnt) atomicAdd(&count_out[item_i], cnt);
+}
+
+extern "C" int isx_knn2_l2_wide_items(const int8_t *desc_dev, const int32_t *nrm_dev, int d_pad, const isx_knn_item *items_dev,
+                                      int n_items, int max_nq, int max_nt, double ratio, int32_t *idx_out_dev,
+                                      float *dist_out_dev, const int64_t *out_start_dev, int32_t *count_out_dev,
+                                      void *stream) {
+    ISX_REQUIRE(d_pad == 32 || d_pad == 64 || d_pad == 128, "d_pad must be 32, 64 or 128 (got %d)", d_pad);
+    ISX_REQUIRE(n_items >= 0 && max_nq >= 0 && max_nt >= 0, "negative size");
+    ISX_REQUIRE(max_nt < (1 << 18), "train set too large: cv2 asserts rows < 2^18 as well (got %d)", max_nt);
+    ISX_REQUIRE((idx_out_dev == nullptr) == (dist_out_dev == nullptr), "idx_out and dist_out must be given together");
+    ISX_REQUIRE(idx_out_dev == nullptr || out_start_dev != nullptr, "out_start_dev is required with idx/dist outputs");
+    if (n_items == 0 || max_nq == 0) return ISX_OK;
+    ISX_REQUIRE(desc_dev && nrm_dev && items_dev, "null device pointer");
+    ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
+    const int nqb = (max_nq + 255) / 256;
+    const int per = isx_items_per_launch(nqb, 256);
+    ISX_REQUIRE(per > 0, "max_nq too large (%d)", max_nq);
+    hipStream_t st = (hipStream_t)stream;
+    for (int off = 0; off < n_items; off += per) { // one launch unless the list is longer than a grid can be
+        const int n = n_items - off < per ? n_items - off : per;
+        const isx_knn_item *it = items_dev + off;
+        const int64_t *os = out_start_dev ? out_start_dev + off : nullptr;
+        int32_t *co = count_out_dev ? count_out_dev + off : nullptr;
+        dim3 grid((unsigned)((int64_t)n * nqb));
+        const int32_t *dw = (const int32_t *)desc_dev;
+        if (d_pad == 32)
+            hipLaunchKernelGGL((knn2_l2_wide_kernel<8>), grid, dim3(256), 0, st, dw, nrm_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+        else if (d_pad == 64)
+            hipLaunchKernelGGL((knn2_l2_wide_kernel<16>), grid, dim3(256), 0, st, dw, nrm_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+        else
+            hipLaunchKernelGGL((knn2_l2_wide_kernel<32>), grid, dim3(256), 0, st, dw, nrm_dev, it, n, nqb, ratio, idx_out_dev, dist_out_dev, os, co);
+    }
+    return isx_launch_status("knn2_l2_wide_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
 // float32 L2.  Block = 4 waves x 32 queries.  D (multiple of 4, <= 128) floats per row, row-major.
 // MFMA 32x32x2: lane (c = lane & 31, h = lane >> 5) feeds A[row c][k] and B[k][query c] with
 // k = h * (D/2) + s at step s -- any bijection of the summation index works as long as A and B agree, and

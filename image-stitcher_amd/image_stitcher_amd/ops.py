@@ -26,11 +26,14 @@ class PreparedDescriptors:
     """Descriptors of one or more images, resident in HBM in the layout the matcher consumes
     (int8 value-128 rows padded to 32/64/128 bytes, per-row key bases and norms)."""
 
-    def __init__(self, desc, cbase, nrm, cin, starts, counts, d, d_pad, max_norm2):
+    def __init__(self, desc, cbase, nrm, cin, starts, counts, d, d_pad, max_norm2, wide=False):
         self.desc, self.cbase, self.nrm, self.cin = desc, cbase, nrm, cin
         self.starts = np.asarray(starts, np.int64)  # first row of every image
         self.counts = np.asarray(counts, np.int64)  # rows of every image
         self.d, self.d_pad, self.max_norm2 = d, d_pad, max_norm2
+        # True: norms beyond ISX_L2_EXACT_LIMIT -- squared distances may collide under sqrtf, so the set is matched by
+        # the kernel that ranks on the float distances themselves (isx_knn2_l2_wide_items), still exactly as cv2
+        self.wide = wide
 
     @property
     def n_images(self):
@@ -41,7 +44,7 @@ class PreparedDescriptors:
         return self.desc.device
 
 
-def prepare_descriptors(des_list, device=None, check_range=True):
+def prepare_descriptors(des_list, device=None, check_range=True, wide_ok=True):
     """des_list: list of (n_i, d) uint8 / float32 arrays or tensors (one per image; None or empty
     allowed).  Float descriptors must be integer valued in [0,255] (cv2 SIFT's are).  Returns
     PreparedDescriptors on `device`."""
@@ -73,11 +76,13 @@ def prepare_descriptors(des_list, device=None, check_range=True):
         raise IsxError(f"descriptor dtype must be uint8 or float32 (got {dtype})")
     src = torch.cat([t.to(device, non_blocking=True) for t in tens], 0).contiguous()
     starts = np.concatenate([[0], np.cumsum(counts)])[:-1]
-    return prepare_descriptor_tensor(src, starts, counts, check_range)
+    return prepare_descriptor_tensor(src, starts, counts, check_range, wide_ok)
 
 
-def prepare_descriptor_tensor(src, starts, counts, check_range=True):
-    """src: (R, d) uint8/float32 device tensor holding all images back to back."""
+def prepare_descriptor_tensor(src, starts, counts, check_range=True, wide_ok=True):
+    """src: (R, d) uint8/float32 device tensor holding all images back to back.  Descriptor sets whose norms exceed
+    the exact range of the MFMA kernels are marked `wide` (matched by isx_knn2_l2_wide_items, equally exact) unless
+    wide_ok=False, which raises NormLimitError instead."""
     _require_cuda(src, "src")
     L = _lib.lib()
     rows, d = src.shape
@@ -92,6 +97,7 @@ def prepare_descriptor_tensor(src, starts, counts, check_range=True):
         check(L.isx_desc_prep(_ptr(src), _lib.U8 if src.dtype == torch.uint8 else _lib.F32, rows, d,
                               _ptr(desc), _ptr(cbase), _ptr(nrm), _ptr(cin), _ptr(stats), _stream()))
         max_norm2 = None
+        wide = False
         if check_range:
             s = stats.cpu().numpy()
             if s[0] & 1:
@@ -99,9 +105,11 @@ def prepare_descriptor_tensor(src, starts, counts, check_range=True):
                                "use the float32 matcher (knn2_f32) instead of the exact integer path")
             max_norm2 = int(s[1])
             if 2 * max_norm2 >= _lib.L2_EXACT_LIMIT:
-                raise NormLimitError(f"descriptor norms too large for the exact integer path "
-                               f"(2*{max_norm2} >= {_lib.L2_EXACT_LIMIT})")
-    return PreparedDescriptors(desc, cbase, nrm, cin, starts, counts, d, d_pad, max_norm2)
+                if not wide_ok:
+                    raise NormLimitError(f"descriptor norms too large for the MFMA integer path "
+                                         f"(2*{max_norm2} >= {_lib.L2_EXACT_LIMIT})")
+                wide = True
+    return PreparedDescriptors(desc, cbase, nrm, cin, starts, counts, d, d_pad, max_norm2, wide)
 
 
 TRAIN_GROUP = 4  # train images an XCD keeps resident while it streams query images past them (4 x 512 KiB of its 4 MiB L2)
@@ -187,7 +195,11 @@ def knn2_l2_items(P, items, ratio, want_matches=False, xcd_order=True, plan=None
             out_dev = torch.from_numpy(out_run[:-1].copy()).to(dev, non_blocking=True)
         if events is not None:
             events[0].record()
-        if want_matches:
+        if P.wide:  # norms beyond the MFMA kernels' exact range: the float-distance-ranking kernel, same outputs
+            max_nt = int(run_items[:, 3].max())
+            check(L.isx_knn2_l2_wide_items(_ptr(P.desc), _ptr(P.nrm), P.d_pad, _ptr(items_dev), m, max_nq, max_nt, float(ratio),
+                                           _ptr(idx), _ptr(dist), _ptr(out_dev), _ptr(counts), _stream()))
+        elif want_matches:
             check(L.isx_knn2_l2_items(_ptr(P.desc), _ptr(P.cbase), _ptr(P.nrm), P.d_pad, _ptr(items_dev), m,
                                       max_nq, float(ratio), _ptr(idx), _ptr(dist), _ptr(out_dev),
                                       _ptr(counts), _stream()))

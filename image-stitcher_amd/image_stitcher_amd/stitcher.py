@@ -246,11 +246,13 @@ class Stitcher:
                 idx, dist, count = ops.knn2_f32(descriptors_1, descriptors_2, self.lowes_ratio_threshold, self._dev())
             else:
                 try:
+                    # (dense byte descriptors whose squared distances leave the range where integer order == cv2's float
+                    # order -- saturated AKAZE/ORB rows -- are matched inside ops by the kernel that ranks on the float
+                    # distances themselves, still exactly)
                     idx, dist, count = ops.knn2_l2(descriptors_1, descriptors_2, self.lowes_ratio_threshold)
-                except (ops.NormLimitError, ops.NotIntegerValuedError):
-                    # dense byte descriptors (e.g. saturated AKAZE/ORB rows): squared distances can exceed the
-                    # range where integer order == cv2's float order; float descriptors that are not integer
-                    # valued (found by the device-side check of isx_desc_prep): the fp32 matcher computes what cv2 does
+                except ops.NotIntegerValuedError:
+                    # float descriptors that are not integer valued (found by the device-side check of
+                    # isx_desc_prep): the fp32 matcher computes what cv2 does
                     f1, f2 = (np.asarray(d, np.float32) for d in (descriptors_1, descriptors_2))
                     idx, dist, count = ops.knn2_f32(f1, f2, self.lowes_ratio_threshold, self._dev())
         return KnnMatches(idx, dist, count)
@@ -702,7 +704,7 @@ class ArbitraryStitcher(Stitcher):
                     P = ops.prepare_descriptors(self.des, device=dev)
                     items = directed_items(mine, P.starts, P.counts)
                     c = ops.knn2_l2_items(P, items, self.lowes_ratio_threshold).view(-1, 2)
-                except (ops.NormLimitError, ops.NotIntegerValuedError):
+                except ops.NotIntegerValuedError:
                     kind = "f32"  # see get_matches
             if kind != "int":
                 des = self.des if kind == "hamming" else [None if d is None else np.asarray(d, np.float32) for d in self.des]

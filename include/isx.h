@@ -108,6 +108,16 @@ int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, cons
                             const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
                             int32_t *count_out_dev, int flags, void *stream);
 
+/* The same matcher without a norm limit: exact L2 kNN-2 + ratio for byte descriptors whose squared distances can
+ * leave the range where sqrtf is injective (2*max||v||^2 >= ISX_L2_EXACT_LIMIT: saturated AKAZE / ORB rows).  Ranks on
+ * the float32 distances cv2.BFMatcher compares (stitcher.py:85, :115), so squared distances that round to the same
+ * float tie to the lowest train index in both slots, as in cv2.  Inputs as isx_knn2_l2_items (the prepared rows and
+ * norms of isx_desc_prep; cbase is not used); VALU dot products, about 10x the MFMA kernel's time.  count_out_dev
+ * optional (caller-zeroed); max_nt < 2^18. */
+int isx_knn2_l2_wide_items(const int8_t *desc_dev, const int32_t *nrm_dev, int d_pad, const isx_knn_item *items_dev,
+                           int n_items, int max_nq, int max_nt, double ratio, int32_t *idx_out_dev, float *dist_out_dev,
+                           const int64_t *out_start_dev, int32_t *count_out_dev, void *stream);
+
 /* Opt-in Hamming matcher (XOR + popcount): the parity target is cv2.BFMatcher(cv2.NORM_HAMMING).knnMatch(k=2)
  * -- NOT what the reference runs by default (stitcher.py:85 builds cv2.BFMatcher(), i.e. L2, for ORB too).
  *   desc_dev : rows x d_pad bytes (d_pad 32 or 64; shorter descriptors zero padded on both sides)

@@ -33,3 +33,7 @@ def test_two_ranks_share_one_gpu(cuda):
     assert d["value"] > 0 and abs(d["value"] - 120 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and "stitch" not in d           # rank-0-at-N=1 extras only
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    b = d["step_breakdown"]                                            # per-phase attribution over the ranks
+    for k in ("kernel_ms", "allgather_ms", "prep_plus_kernel_ms", "gather_ms"):
+        assert 0 <= b[k]["min"] <= b[k]["max"]
+    assert b["kernel_ms"]["max"] > 0 and b["host_ms_rank0"] >= 0

@@ -66,11 +66,17 @@ def test_knn2_float_noninteger_rejected(cuda):
         ops.knn2_l2(q, q)
 
 
-def test_knn2_norm_limit_rejected(cuda):
+def test_knn2_norm_limit_routes_to_the_wide_kernel(cuda, orc):
+    """Norms beyond ISX_L2_EXACT_LIMIT: the MFMA path refuses when asked to (wide_ok=False), the default routes the
+    set to the float-distance-ranking kernel -- all-255 rows are all at distance 0: both slots = lowest indices."""
     from image_stitcher_amd import ops
     q = np.full((8, 128), 255, np.uint8)
-    with pytest.raises(ops.IsxError):
-        ops.knn2_l2(q, q)
+    with pytest.raises(ops.NormLimitError):
+        ops.prepare_descriptors([q, q], wide_ok=False)
+    idx, dist, cnt = ops.knn2_l2(q, q)
+    ridx, rdist = orc.knn2(q, q)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(idx.cpu().numpy(), np.tile([0, 1], (8, 1)))
+    assert np.array_equal(dist.cpu().numpy(), rdist) and int(cnt.item()) == 0
 
 
 def test_knn2_items_batched_counts(cuda, orc):

@@ -110,3 +110,54 @@ def test_hamming_counts_on_the_fp4_matrix_pipe(cuda, orc, d):
     with pytest.raises(ops.IsxError):
         ops.alt_item_counts([rng.integers(0, 256, (8, 61), dtype=np.uint8)] * 2, lambda st, ct: np.array([(0, 8, 8, 8)], np.int32),
                             "hamming", 0.65, cuda, hamming_impl="fp4")
+
+
+@pytest.mark.parametrize("d", [61, 32, 128])
+def test_saturated_byte_descriptors_stay_exact(cuda, orc, d):
+    """Dense / saturated byte descriptors (AKAZE's 61 bytes, ORB's 32, 128): squared distances reach 8.3e6, where
+    sqrtf is no longer injective on integers, so different integer distances collide as float32 and cv2 keeps the
+    lower train index.  The MFMA kernels rank on integers; such sets go to isx_knn2_l2_wide_items, which ranks on the
+    float distances -- indices and distances bit-identical to the oracle, planted float-collisions included."""
+    import torch
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(17 + d)
+    nq, nt = 300, 700
+    q = rng.choice(np.array([0, 1, 254, 255], np.uint8), (nq, d))
+    t = rng.choice(np.array([0, 1, 2, 253, 254, 255], np.uint8), (nt, d))
+    q[0] = 255
+    t[5] = 0                      # the largest possible distance: d * 255^2
+    t[9] = 0
+    t[9, 0] = 1                   # integer distance differs by 509 from row 5's: may or may not collide as float
+    # planted float collisions: rows whose integer distances to q[1] differ by 1 at s ~ 6e6 (sqrtf spacing > 1 there)
+    q[1] = 255
+    base = np.zeros(d, np.uint8)
+    t[20], t[21] = base, base.copy()
+    t[21, 1] = 1                  # s differs from row 20's by 2*255 - 1
+    P = ops.prepare_descriptors([q, t])
+    if d * 255 * 255 * 2 >= 4197200:
+        assert P.wide
+    idx, dist, cnt = ops.knn2_l2(q, t, 0.65)
+    ridx, rdist = orc.knn2(q, t)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(dist.cpu().numpy().view(np.int32), rdist.view(np.int32))
+    gq, _ = orc.ratio_filter(ridx, rdist, 0.65)
+    assert int(cnt.item()) == len(gq)
+    # count-only form through the item interface (what get_collections uses)
+    items = np.array([[0, nq, nq, nt], [nq, nt, 0, nq]], np.int32)
+    c = ops.knn2_l2_items(P, items, 0.65).cpu().numpy()
+    assert c[0] == len(gq) and c[1] == orc.match_count(t, q, 0.65)
+
+
+def test_wide_kernel_equals_mfma_kernel_inside_the_limit(cuda, orc):
+    """Inside the exact range both kernels must give the same answer: SIFT-like rows forced through the wide kernel."""
+    import torch
+    from image_stitcher_amd import ops
+    from image_stitcher_amd.synthetic import overlapping_crops_descriptors
+    des, _ = overlapping_crops_descriptors(seed=5, n_scenes=1, imgs_per_scene=2, kp=900, step=200)
+    P = ops.prepare_descriptors([des[0], des[1]])
+    assert not P.wide
+    items = np.array([[0, 900, 900, 900]], np.int32)
+    c0, (i0, d0, _) = ops.knn2_l2_items(P, items, 0.65, want_matches=True, xcd_order=False)
+    P.wide = True
+    c1, (i1, d1, _) = ops.knn2_l2_items(P, items, 0.65, want_matches=True, xcd_order=False)
+    assert torch.equal(i0, i1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32)) and torch.equal(c0, c1)

@@ -368,11 +368,11 @@ def test_overridden_seams_are_honoured(cuda, world, tmp_path, blender):
     assert calls["warp"] == 3 and calls["merge"] == 3 and calls["detect"] == 4   # ROI detection from the 2nd stitch on
 
 
-def test_saturated_byte_descriptors_fall_back_to_fp32(cuda, orc):
+def test_saturated_byte_descriptors_stay_on_an_exact_path(cuda, orc):
     """Dense binary descriptors read as bytes (AKAZE/ORB rows full of 0xFF) can push squared L2 distances
     past 2^22, where sqrtf stops being injective and the integer ranking is no longer provably cv2's float
-    ranking: the int8 path refuses (NormLimitError) and the stitcher routes the pair through the fp32-MFMA
-    matcher, which computes the same float distances as cv2.BFMatcher() does."""
+    ranking: the MFMA path refuses such a set (wide_ok=False) and the host layer matches it with the kernel that
+    ranks on the float distances cv2 compares -- indices AND distances bit-identical to the oracle."""
     from image_stitcher_amd import ArbitraryStitcher, Stitcher, ops
     rng = np.random.default_rng(61)
     base = np.where(rng.random((400, 61)) < 0.8, 255, rng.integers(0, 256, (400, 61))).astype(np.uint8)
@@ -381,12 +381,12 @@ def test_saturated_byte_descriptors_fall_back_to_fp32(cuda, orc):
     flip = rng.random(t.shape) < 0.05
     t[flip] = rng.integers(0, 256, int(flip.sum()), dtype=np.uint8)
     with pytest.raises(ops.NormLimitError):
-        ops.knn2_l2(q, t)
+        ops.prepare_descriptors([q, t], wide_ok=False)
     st = Stitcher(log_level=3)
     m = st.get_matches(q, t, 2)
     ridx, rdist = orc.knn2(q, t)
     assert np.array_equal(m.idx.cpu().numpy(), ridx)
-    assert np.abs(m.dist.cpu().numpy() - rdist).max() <= 1e-4 * rdist.max()
+    assert np.array_equal(m.dist.cpu().numpy().view(np.int32), rdist.view(np.int32))
     good = st.filter_matches(m)
     gq, gt = orc.ratio_filter(ridx, rdist, 0.65)
     assert np.array_equal(good.good_q, gq) and np.array_equal(good.good_t, gt)
