@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
                                                              uint8_t *mosaic_q, int64_t mpitch, int qx0, int qy0,
                                                              int qw, int qh, const int32_t *__restrict__ rows,
                                                              const int32_t *__restrict__ cols, int feather,
-                                                             const int32_t *__restrict__ res,
+                                                             int clip_y0, int clip_y1, const int32_t *__restrict__ res,
                                                              int32_t *__restrict__ part) {
     // per-workgroup partial {minx, miny, maxx, maxy, zeroed, dirty} (plain stores, folded on the host)
     int32_t *mypart = part + 6 * (blockIdx.y * gridDim.x + blockIdx.x);
@@ -510,7 +510,8 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
         for (int i = 0; i < 2; i++) {
             const int ly = min(lyb + 4 * i, qh - 1);
             quad_load<C>(wbuf + (int64_t)ly * wpitch, lx, qw, pw[i]);
-            quad_load<C>(mosaic_q + (int64_t)ly * mpitch, lx, qw, pr[i]);
+            // (rows of another strip are not addressable in this GPU's arena)
+            quad_load<C>(mosaic_q + (int64_t)ly * mpitch, lx, (qy0 + ly >= clip_y0 && qy0 + ly < clip_y1) ? qw : 0, pr[i]);
             const int4 e = rt[ly];
             L[i] = e.z;
             R[i] = e.w;
@@ -523,7 +524,10 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
         }
     }
     const int found = res[R_WBBOX + 4], rows_ok = res[R_ROWS_OK];
-    const int gx0 = res[R_ROI + 0], gy0 = res[R_ROI + 1], gx1 = res[R_ROI + 2], gy1 = res[R_ROI + 3];
+    // ROI rows [ry0, ry1) clip the feather bands; rows outside [clip_y0, clip_y1) belong to another strip of the mosaic
+    // (another GPU) and are never read or written here: [gy0, gy1) is what this call blends
+    const int gx0 = res[R_ROI + 0], ry0 = res[R_ROI + 1], gx1 = res[R_ROI + 2], ry1 = res[R_ROI + 3];
+    const int gy0 = max(ry0, clip_y0), gy1 = min(ry1, clip_y1);
     // alpha = k / feather for k = 0 .. feather (proc.py:220, :225, :239, :244), divided once per workgroup:
     // the same IEEE quotient as the reference's per-pixel division
     __shared__ double ftab[64];
@@ -579,7 +583,7 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
                 // free: a factor that does not apply is read as ftab[feather] = 1.0 (an exact no-op), so the four
                 // LDS reads of a pixel are in flight together
                 const int xe = L[i] + feather < gx1 ? L[i] + feather : gx1, xb = R[i] - feather > gx0 ? R[i] - feather : gx0;
-                const int ye = T[k] + feather < gy1 ? T[k] + feather : gy1, yb = B[k] - feather > gy0 ? B[k] - feather : gy0;
+                const int ye = T[k] + feather < ry1 ? T[k] + feather : ry1, yb = B[k] - feather > ry0 ? B[k] - feather : ry0;
                 const int i0 = (R[i] >= 0 && xx >= L[i] && xx < xe) ? xx - L[i] : feather;
                 const int i1 = (R[i] >= 0 && xx >= xb && xx <= R[i]) ? R[i] - xx : feather;
                 const int i2 = (B[k] >= 0 && Y >= T[k] && Y < ye) ? Y - T[k] : feather;
@@ -638,16 +642,19 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
 template <int C, bool PERSP, bool CLASSIC>
 __global__ void __launch_bounds__(1024) frame_warp_alpha_kernel(const uint8_t *__restrict__ src, const WarpParams P,
                                                                uint8_t *mosaic_q, int64_t mpitch, int nchunk,
-                                                               double contrib, double one_minus,
+                                                               double contrib, double one_minus, int clip_y0, int clip_y1,
                                                                int32_t *__restrict__ rows) {
     const int ly = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int gl = INT_MAX, gr = -1, ml = INT_MAX, mr = -1, zeroed = 0, dirty = 0;
     uint8_t *mrow = mosaic_q + (int64_t)ly * mpitch;
+    // rows of another strip of the mosaic (another GPU): the warped row still counts for bbox(warped), the mosaic is
+    // neither read nor written
+    const bool mine = P.dy0 + ly >= clip_y0 && P.dy0 + ly < clip_y1;
     for (int chunk = wave; chunk < nchunk; chunk += nw) {
         const int lx = chunk * 256 + 4 * lane;
         const int nv = min(4, max(0, P.dw - lx));
         uint32_t px[4], pb[4] = {0u, 0u, 0u, 0u}, po[4];
-        if (nv > 0) quad_load<C>(mrow, lx, P.dw, pb);
+        if (nv > 0 && mine) quad_load<C>(mrow, lx, P.dw, pb);
         warp_quad<C, PERSP, CLASSIC>(src, P, P.dx0 + lx, P.dy0 + ly, nv, px);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -658,6 +665,7 @@ __global__ void __launch_bounds__(1024) frame_warp_alpha_kernel(const uint8_t *_
                 gl = min(gl, X);
                 gr = max(gr, X);
             }
+            if (!mine) continue;
             if (gray_px<C>(po[i]) != 0) {
                 ml = min(ml, X);
                 mr = max(mr, X);
@@ -666,7 +674,7 @@ __global__ void __launch_bounds__(1024) frame_warp_alpha_kernel(const uint8_t *_
                 if (gray_px<C>(pb[i]) != 0) zeroed = 1;
             }
         }
-        if (nv > 0) quad_store<C>(mrow, lx, P.dw, po);
+        if (nv > 0 && mine) quad_store<C>(mrow, lx, P.dw, po);
     }
     __shared__ int red[FRAME_MAX_WAVES][6];
     gl = wave_min(gl), gr = wave_max(gr), ml = wave_min(ml), mr = wave_max(mr);
@@ -717,8 +725,9 @@ static void empty_result(int32_t *r) {
 
 extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x,
                                int src_y, const double *M_host, int model, int arith, int canvas_w, int canvas_h,
-                               uint8_t *mosaic_q_dev, int64_t mpitch, int q_x0, int q_y0, int q_w, int q_h, int blender,
-                               double ref_contrib, int feather, int32_t *result_host, void *stream) {
+                               uint8_t *mosaic_q_dev, int64_t mpitch, int q_x0, int q_y0, int q_w, int q_h, int clip_y0,
+                               int clip_y1, int blender, double ref_contrib, int feather, int32_t *result_host,
+                               void *stream) {
     ISX_REQUIRE(ctx, "null ctx");
     ISX_REQUIRE(c == 1 || c == 3, "channels must be 1 or 3 (got %d)", c);
     ISX_REQUIRE(model == ISX_MODEL_AFFINE_PARTIAL || model == ISX_MODEL_HOMOGRAPHY, "bad model %d", model);
@@ -777,10 +786,10 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
                            canvas_h, 50, ctx->mask, nchunk, ctx->cols, ctx->out_dev);
         if (c == 3)
             hipLaunchKernelGGL((frame_gradient_kernel<3>), gb, dim3(256), 0, st, ctx->wbuf, wpitch, mosaic_q_dev, mpitch, q_x0,
-                               q_y0, q_w, q_h, ctx->rows, ctx->cols, feather, ctx->out_dev, ctx->out_dev + R_INTS);
+                               q_y0, q_w, q_h, ctx->rows, ctx->cols, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
         else
             hipLaunchKernelGGL((frame_gradient_kernel<1>), gb, dim3(256), 0, st, ctx->wbuf, wpitch, mosaic_q_dev, mpitch, q_x0,
-                               q_y0, q_w, q_h, ctx->rows, ctx->cols, feather, ctx->out_dev, ctx->out_dev + R_INTS);
+                               q_y0, q_w, q_h, ctx->rows, ctx->cols, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
         ctx->fold_n = n_part;
         ctx->pending = 1;
     } else {
@@ -789,7 +798,7 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
         const double one_minus = 1 - ref_contrib; // Python: (1-ref_image_contrib)
 #define ISX_FA_LAUNCH(CC, PP, AA)                                                                                     \
     hipLaunchKernelGGL((frame_warp_alpha_kernel<CC, PP, AA>), dim3(q_h), dim3(row_threads), 0, st, src_dev, P, mosaic_q_dev, \
-                       mpitch, nchunk, ref_contrib, one_minus, ctx->out_dev + R_INTS)
+                       mpitch, nchunk, ref_contrib, one_minus, clip_y0, clip_y1, ctx->out_dev + R_INTS)
         if (c == 3) {
             if (persp && classic) ISX_FA_LAUNCH(3, true, true);
             else if (persp) ISX_FA_LAUNCH(3, true, false);

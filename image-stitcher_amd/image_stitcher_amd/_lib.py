@@ -59,7 +59,7 @@ SIGNATURES = {
     "isx_ctx_create": (c_int, [c_void_p]),
     "isx_ctx_destroy": (c_int, [c_void_p]),
     "isx_frame_blend": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_int,
-                                c_int, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_double,
+                                c_int, c_int, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double,
                                 c_int, c_void_p, c_void_p]),
     "isx_frame_match": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p]),

@@ -625,29 +625,33 @@ def frame_result(ctx):
 
 
 def frame_blend(ctx, src, M, perspective, src_xy, canvas_wh, arena_t, canvas_to_arena, q_rect, blender,
-                contrib=0.5, feather=10, arith="f32", fetch=True):
+                contrib=0.5, feather=10, arith="f32", fetch=True, clip_rows=None):
     """isx_frame_blend: warp `src` (pasted at src_xy of the virtual canvas) by M and blend it IN PLACE into the
     mosaic held by arena_t (canvas (X, Y) is arena pixel (X + canvas_to_arena[0], Y + canvas_to_arena[1])), only over
     the canvas rectangle q_rect = (x0, y0, w, h).  Synchronous; returns the int32 result block as a dict of python
-    ints / tuples.  fetch=False only queues the kernels (returns None; frame_result() reads the block later)."""
+    ints / tuples.  fetch=False only queues the kernels (returns None; frame_result() reads the block later).
+    clip_rows = (y0, y1): arena_t holds only the canvas rows [y0, y1) of the mosaic (one strip of a mosaic partitioned over
+    several GPUs): only those rows are read or written and only they must be addressable in arena_t."""
     p, sh, sw, c, spitch = _img_args(src, "src")
     pa, ah, aw, ac, apitch = _img_args(arena_t, "arena")
     if ac != c:
         raise IsxError("arena and frame differ in channels")
     qx0, qy0, qw, qh = (int(v) for v in q_rect)
     ax0, ay0 = qx0 + int(canvas_to_arena[0]), qy0 + int(canvas_to_arena[1])
-    if qw > 0 and qh > 0 and (ax0 < 0 or ay0 < 0 or ax0 + qw > aw or ay0 + qh > ah):
-        raise IsxError("frame_blend: Q lies outside the arena")
+    cy0, cy1 = (0, int(canvas_wh[1])) if clip_rows is None else (int(clip_rows[0]), int(clip_rows[1]))
+    ry0, ry1 = max(qy0, cy0), min(qy0 + qh, cy1)  # rows of Q this arena must hold
+    if qw > 0 and ry1 > ry0 and (ax0 < 0 or ax0 + qw > aw or ry0 + int(canvas_to_arena[1]) < 0 or ry1 + int(canvas_to_arena[1]) > ah):
+        raise IsxError("frame_blend: the rows of Q inside the clip lie outside the arena")
     M = np.ascontiguousarray(M, np.float64)
     if M.shape != ((3, 3) if perspective else (2, 3)):
         raise IsxError(f"M has shape {M.shape}")
-    mq = ctypes.c_void_p(arena_t.data_ptr() + ay0 * apitch + ax0 * c)
+    mq = ctypes.c_void_p(arena_t.data_ptr() + ay0 * apitch + ax0 * c)  # (may lie outside the arena when clipped: never dereferenced there)
     r = ctx._res
     with torch.cuda.device(src.device):
         check(_lib.lib().isx_frame_blend(ctx._h, p, sh, sw, c, spitch, int(src_xy[0]), int(src_xy[1]),
                                          M.ctypes.data_as(ctypes.c_void_p),
                                          _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL,
-                                         WARP_ARITH[arith], int(canvas_wh[0]), int(canvas_wh[1]), mq, apitch, qx0, qy0, qw, qh,
+                                         WARP_ARITH[arith], int(canvas_wh[0]), int(canvas_wh[1]), mq, apitch, qx0, qy0, qw, qh, cy0, cy1,
                                          int(blender), float(contrib), int(feather),
                                          r.ctypes.data_as(ctypes.c_void_p) if fetch else None, _stream()))
     return _frame_result_dict(r) if fetch else None

@@ -28,6 +28,7 @@ from . import ops
 from .async_save import AsyncImageWriter, write_image
 from .detect import make_detector
 from .device_image import DeviceImage, MosaicArena
+from .strips import StripMosaic
 from .pairs import components_from_counts, directed_items, gather_counts, shard_pairs, unordered_pairs
 from .utils.logger import LogWrapper
 from .utils.proc import (crop_image, get_corners_from_image, get_padded_images, get_roi_from_corners,  # noqa: F401
@@ -334,6 +335,11 @@ class Stitcher:
     @timer
     def save_last_stitch(self, stitch, filename):
         filepath = os.path.join(self.output_dir, filename)
+        if isinstance(stitch, StripMosaic):
+            full = np.asarray(stitch)  # collective: every rank takes part in the gather, rank 0 writes the file
+            if stitch.rank != 0:
+                return
+            stitch = full
         if self.async_save:
             if self._writer is None:
                 self._writer = AsyncImageWriter(self._dev())
@@ -366,6 +372,8 @@ class Stitcher:
             img = img._host  # the frame came from the host: no download needed
         x0, y0 = max(0, min(W, p1[0])), max(0, min(H, p1[1]))
         x1, y1 = max(x0, min(W, p2[0])), max(y0, min(H, p2[1]))
+        if isinstance(img, StripMosaic):  # rows live on several ranks: assembled by one all_gather (zeros outside)
+            return img.region(x0 - ox, y0 - oy, x1 - ox, y1 - oy)
         if x0 >= ox and y0 >= oy and x1 <= ox + img.shape[1] and y1 <= oy + img.shape[0] and x1 > x0 and y1 > y0:
             # the region lies inside the image (the usual case): a view of the host frame / a download of
             # just that part of the resident mosaic -- no zero canvas, no second copy
@@ -548,7 +556,7 @@ class Stitcher:
         tp = time.perf_counter()
         dev = self._dev()
         img_d = DeviceImage.from_any(arg_img, dev)
-        ref_d = DeviceImage.from_any(arg_ref, dev)
+        ref_d = arg_ref if isinstance(arg_ref, StripMosaic) else DeviceImage.from_any(arg_ref, dev)
         ih, iw = img_d.shape[:2]
         rh, rw = ref_d.shape[:2]
         C = img_d.channels
@@ -625,11 +633,17 @@ class Stitcher:
             # the reference passes None to cv2.warp* here, which raises (stitcher.py:208, :216)
             raise RuntimeError("transform estimation failed (cv2 would raise on M=None)")
         M = np.asarray(M, np.float64)
-        if self._overridden("warp_target") or self._overridden("merge"):
+        if isinstance(ref_d, StripMosaic):
+            if self._overridden("warp_target") or self._overridden("merge") or self._overridden("detectAndComputeFromCorners"):
+                raise ops.IsxError("a strip-partitioned mosaic is blended by the library's frame pipeline only "
+                                   "(overridden warp_target / merge / detectAndComputeFromCorners seams are not supported)")
+            with torch.cuda.device(dev):
+                mosaic, wcorners = ref_d.blend(self, img_d, M, W, H, rox, roy, ox, oy)
+        elif self._overridden("warp_target") or self._overridden("merge"):
             return self._stitch_tail_via_seams(img_d, ref_d, M, tf)
-
-        with torch.cuda.device(dev):
-            mosaic, wcorners = self._blend_resident(img_d, ref_d, M, W, H, rox, roy, ox, oy)
+        else:
+            with torch.cuda.device(dev):
+                mosaic, wcorners = self._blend_resident(img_d, ref_d, M, W, H, rox, roy, ox, oy)
         tp = self._phase("warp+blend", tp)
 
         if self.consecutive_range is not None:
@@ -640,7 +654,7 @@ class Stitcher:
 
         if mosaic is None:
             return None  # crop_image returned False (stitcher.py:226-227)
-        if not self.resident:
+        if not self.resident and not isinstance(mosaic, StripMosaic):
             mosaic = np.ascontiguousarray(mosaic.numpy())
         return mosaic, corners, tf
 
@@ -665,6 +679,10 @@ class ArbitraryStitcher(Stitcher):
         else:
             self.tqdm = with_tqdm
         self.dist_group = None  # torch.distributed group to shard get_collections over (None = default)
+        # extension: strip_group = a torch.distributed process group (or True for the default group):
+        # stitch_collections then keeps every mosaic partitioned into row strips over the group's ranks (strips.py); all
+        # ranks must call stitch_collections with the same images; rank 0 writes the blend_i.png files
+        self.strip_group = None
 
     @timer
     def update_all_keypoints_and_descriptors(self):
@@ -753,6 +771,11 @@ class ArbitraryStitcher(Stitcher):
                 continue
             ref = idxs[0]
             reference_image = self.images[ref]
+            if self.strip_group is not None:
+                import torch.distributed as dist
+                group = None if self.strip_group is True else self.strip_group
+                reference_image = StripMosaic.from_image(np.asarray(reference_image), group if group is not None else dist.group.WORLD,
+                                                         self._dev())
             idxs.remove(ref)
             key_points_broken = False
             while len(idxs) != 0:

@@ -249,6 +249,10 @@ int isx_ctx_destroy(isx_ctx *ctx);
  *   Q = [q_x0, q_x0+q_w) x [q_y0, q_y0+q_h) : a canvas rectangle that contains every warped pixel that can be
  *       non-zero, plus >= 52 px on every side for the gradient blender's ROI (clipped to the canvas);
  *   mosaic_q_dev / mpitch : the arena pixel under canvas (q_x0, q_y0); all of Q must lie inside the arena;
+ *   clip_y0 / clip_y1 : canvas rows [clip_y0, clip_y1) of the mosaic that THIS arena holds (0, canvas_h: all of it).  A
+ *       mosaic partitioned into row strips over several GPUs is blended by one call per GPU with the same
+ *       frame and M: the warp, bbox(warped), ROI and extents are computed for the whole frame on every GPU (they do not
+ *       depend on the mosaic), only rows inside the clip are read or written, and [9..15] then describe this strip only;
  *   blender / ref_contrib / feather : stitcher.py:153-156, utils/proc.py:48 `image1_contribution`, :192 (10).
  * The mosaic is updated IN PLACE.  SYNCHRONOUS when result_host is given: returns after the kernels finished
  * (one small device-to-host copy + stream synchronisation).  With result_host == NULL the kernels are only
@@ -267,8 +271,8 @@ int isx_ctx_destroy(isx_ctx *ctx);
  *   [17]     1 if the blend ran */
 int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
                     const double *M_host, int model, int arith, int canvas_w, int canvas_h, uint8_t *mosaic_q_dev,
-                    int64_t mpitch, int q_x0, int q_y0, int q_w, int q_h, int blender, double ref_contrib, int feather,
-                    int32_t *result_host, void *stream);
+                    int64_t mpitch, int q_x0, int q_y0, int q_w, int q_h, int clip_y0, int clip_y1, int blender,
+                    double ref_contrib, int feather, int32_t *result_host, void *stream);
 int isx_frame_result(isx_ctx *ctx, int32_t *result_host, void *stream);
 /* Device address of the warped image staged by the last gradient-path isx_frame_blend (Q-sized, pitch q_w * c). */
 int isx_frame_warped(isx_ctx *ctx, const uint8_t **wbuf_dev_out);

@@ -71,12 +71,12 @@ int main() {
         int32_t res[ISX_FRAME_RESULT_INTS];
         uint8_t *mq = arena + ((size_t)dy0 * CW + dx0) * C;
         for (int blender = 1; blender >= 0; blender--) {
-            t = time_us(200, [&] { IK(isx_frame_blend(ctx, src, sh, sw, C, sw * C, sx, sy, M, 0, 0, CW, CH, mq, (int64_t)CW * C, dx0, dy0, dw, dh, blender, 0.5, 10, nullptr, 0)); });
+            t = time_us(200, [&] { IK(isx_frame_blend(ctx, src, sh, sw, C, sw * C, sx, sy, M, 0, 0, CW, CH, mq, (int64_t)CW * C, dx0, dy0, dw, dh, 0, CH, blender, 0.5, 10, nullptr, 0)); });
             IK(isx_frame_result(ctx, res, 0));
             printf("frame: isx_frame_blend %-8s %7.2f us  algorithmic %6.0f GB/s  (wbbox %d,%d-%d,%d roi %d,%d-%d,%d done %d rows_ok %d zeroed %d)\n",
                    blender ? "gradient" : "alpha", t, (src_b + 2 * roi_b) / t / 1e3, res[0], res[1], res[2], res[3], res[5], res[6], res[7], res[8], res[17], res[16], res[14]);
         }
-        t = time_us(50, [&] { IK(isx_frame_blend(ctx, src, sh, sw, C, sw * C, sx, sy, M, 0, 0, CW, CH, mq, (int64_t)CW * C, dx0, dy0, dw, dh, 1, 0.5, 10, res, 0)); });
+        t = time_us(50, [&] { IK(isx_frame_blend(ctx, src, sh, sw, C, sw * C, sx, sy, M, 0, 0, CW, CH, mq, (int64_t)CW * C, dx0, dy0, dw, dh, 0, CH, 1, 0.5, 10, res, 0)); });
         printf("frame: isx_frame_blend gradient, synchronous (with result read-back) %7.2f us per call\n", t);
         IK(isx_ctx_destroy(ctx));
     }
