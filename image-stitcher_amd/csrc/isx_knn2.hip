@@ -24,6 +24,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define ISX_B2 4194304 /* 1 << 22: count kernel's cin bias, keeps h in [2^20, 2^23) for valid rows; 0 = absent */
 #ifndef ISX_COUNT_WPS
@@ -183,7 +184,7 @@ extern "C" int isx_desc_prep(const void *src_dev, int src_dtype, int64_t rows, i
 
 // ------------------------------------------------------------------------------------------------
 // kNN-2 + ratio kernel.  Block = 4 waves x 64 queries; train rows stream through LDS in 128-row
-// chunks (double buffered, register staged).  blockIdx -> (item, query block) is XCD aware: blocks
+// chunks (three LDS buffers filled by LDS-DMA).  blockIdx -> (item, query block) is XCD aware: blocks
 // that share blockIdx%8 share an XCD/L2, so item e is served entirely by XCD e%8 and the caller
 // orders items so that consecutive items on one XCD share their train image.
 // ------------------------------------------------------------------------------------------------
@@ -207,7 +208,7 @@ knn2_l2_kernel(const int8_t *__restrict__ desc, const uint32_t *__restrict__ cba
     constexpr int SH = (KS == 4) ? 1 : (KS == 2) ? 2 : 3;
     constexpr int CHUNK = 128;
     constexpr int BUF = CHUNK * DP + CHUNK * 4;
-    __shared__ __align__(16) unsigned char smem[2 * BUF];
+    __shared__ __align__(16) unsigned char smem[3 * BUF];
 
     const int id = blockIdx.x;
     const int xcd = id & 7;
@@ -243,18 +244,35 @@ knn2_l2_kernel(const int8_t *__restrict__ desc, const uint32_t *__restrict__ cba
     }
 
     const int n_chunks = (nt + CHUNK - 1) / CHUNK;
-    v4i st[KS];
-    unsigned st_cb = 0;
 
-    auto load_chunk = [&](int c) {
+    // Descriptor rows go to LDS by LDS-DMA exactly as in the count kernels below (no staging registers, swizzle
+    // applied on the global side, rows beyond nt zero-filled by the buffer range check); three buffers, chunk c+2
+    // in flight while chunk c is consumed.  The 128 ranking codes of a chunk (cbase + position code) still pass
+    // through a register: the position code is added on the way, once per row instead of once per distance.
+    const __amdgpu_buffer_rsrc_t rs_desc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(desc + (int64_t)it.t_start * DP), 0, nt * DP, 0x00020000);
+    constexpr int ROWS_PP = 1024 / DP;
+    constexpr int PIECES = CHUNK * DP / 1024;
+    constexpr int PPW = (PIECES + 3) / 4;
+    const int r_in = lane / SLOTS;
+    const int lane_voff = r_in * DP + (((lane % SLOTS) ^ (((wave * ROWS_PP + r_in) >> SH) & (SLOTS - 1))) << 4);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const unsigned smem_lds = (unsigned)(size_t)smem;
+    auto stage_desc = [&](int c, int bufi) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-        for (int i = 0; i < KS; i++) {
-            const int u = tid + 256 * i;
-            const int row = u / SLOTS, slot = u % SLOTS;
-            const int jl = c * CHUNK + row;
-            st[i] = (jl < nt) ? *(const v4i *)(desc + (int64_t)(it.t_start + jl) * DP + slot * 16)
-                              : v4i{0, 0, 0, 0};
+        for (int k = 0; k < PPW; k++) {
+            const int piece = wv + 4 * k;
+            if (PIECES % 4 != 0 && piece >= PIECES) break;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_desc, (lds_ptr_t)(smem_lds + bufi * BUF + piece * 1024), 16, lane_voff,
+                                                     c * (CHUNK * DP) + piece * 1024, 0, 0);
         }
+    };
+#pragma clang diagnostic pop
+    unsigned st_cb = 0;
+    auto load_cb = [&](int c) {
         if (tid < CHUNK) {
             const int jl = c * CHUNK + tid;
             const int tt = (c & 3) * 4 + (tid >> 5);
@@ -263,26 +281,29 @@ knn2_l2_kernel(const int8_t *__restrict__ desc, const uint32_t *__restrict__ cba
             st_cb = (jl < nt) ? (cbase[it.t_start + jl] + (unsigned)code) : 0u;
         }
     };
-    auto store_chunk = [&](int buf) {
-        unsigned char *base = smem + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < KS; i++) {
-            const int u = tid + 256 * i;
-            const int row = u / SLOTS, slot = u % SLOTS;
-            *(v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4)) = st[i];
-        }
-        if (tid < CHUNK) *(unsigned *)(base + CHUNK * DP + tid * 4) = st_cb;
+    auto store_cb = [&](int bufi) {
+        if (tid < CHUNK) *(unsigned *)(smem + bufi * BUF + CHUNK * DP + tid * 4) = st_cb;
     };
 
     if (n_chunks > 0) {
-        load_chunk(0);
-        store_chunk(0);
+        stage_desc(0, 0);
+        load_cb(0);
+        store_cb(0);
+    }
+    if (n_chunks > 1) {
+        stage_desc(1, 1);
+        load_cb(1);
+        store_cb(1);
     }
     __syncthreads();
 
+    int buf = 0;
     for (int c = 0; c < n_chunks; c++) {
-        const int buf = c & 1;
-        if (c + 1 < n_chunks) load_chunk(c + 1);
+        const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
+        if (c + 2 < n_chunks) { // buf2 was last read before the previous barrier
+            stage_desc(c + 2, buf2);
+            load_cb(c + 2);
+        }
         const unsigned char *base = smem + buf * BUF;
 #pragma unroll
         for (int tl = 0; tl < 4; tl++) {
@@ -318,8 +339,9 @@ knn2_l2_kernel(const int8_t *__restrict__ desc, const uint32_t *__restrict__ cba
                 }
             }
         }
-        if (c + 1 < n_chunks) store_chunk(buf ^ 1);
+        if (c + 2 < n_chunks) store_cb(buf2);
         __syncthreads();
+        buf = buf1;
 
         if ((c & 3) == 3 || c == n_chunks - 1) {
             const int seg = c >> 2;
@@ -754,18 +776,24 @@ knn2_count_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ n
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same count kernel on v_mfma_i32_16x16x64_i8 (128-byte rows, L2 only).  Same staging, same LDS layout,
+// The same count kernel on v_mfma_i32_16x16x64_i8 (128- and 64-byte rows; 32-byte rows stay on knn2_count_kernel<1>: one
+// 32x32x32 instruction already covers the whole row and the kernel is bound by the fold there, not by the matrix pipe).
+// KIND 1 = the FP4 Hamming rows on v_mfma_scale_f32_16x16x128_f8f6f4: built, bit-identical, and measured 5.5 % slower
+// than the 32x32x64 chain (profiles/r02_shape_ab.md), so it is compiled in only as an experiment.  Same staging, same LDS layout,
 // same fold arithmetic and epilogue; what changes is the tile shape: a unit is two 16-row train tiles against
 // the wave's four 16-query column blocks (16 instructions of 16K MACs = the 8 x 32K of the 32x32x32 kernel),
 // a lane owns query (lane & 15) of each column block and sees train rows 4 (lane >> 4) + i of a tile, so the
 // four lanes that share a query merge at the end.  Per MAC the instruction writes half as many accumulator
 // values as 32x32x32; tools/mfma_rate.hip ("shape") measures it 9-11 % faster under the power limit.
 // ------------------------------------------------------------------------------------------------
+template <int KS16, int KIND = 0>
 __global__ void __launch_bounds__(64 * ISX_COUNT_WAVES, ISX_COUNT_WPS)
 knn2_count16_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm, const int32_t *__restrict__ cin,
                     const isx_knn_item *__restrict__ items, int n_items, int nqb, double ratio,
                     int32_t *__restrict__ count_out, int flags) {
-    constexpr int DP = 128, SLOTS = 8, SH = 1, CHUNK = 128;
+    // KS16 = 64-byte K steps per row: 2 for 128-byte rows (SIFT; the 256 FP4 nibbles of KIND 1), 1 for 64-byte rows (AKAZE)
+    constexpr int DP = 64 * KS16, SLOTS = DP / 16, SH = KS16 == 2 ? 1 : 2, CHUNK = 128;
+    static_assert(KIND == 0 || KS16 == 2, "the FP4 Hamming rows are 128 bytes");
     constexpr int BUF = CHUNK * DP + CHUNK * 4;
     __shared__ __align__(16) unsigned char smem[3 * BUF];
 
@@ -786,13 +814,13 @@ knn2_count16_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__
     const int nt = it.nt;
     const bool wave_live = q0 < it.nq;
 
-    v4i qf[NCB][2];
+    v4i qf[NCB][KS16];
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
         const int qi = q0 + cb * 16 + col;
         const v4i *p = (const v4i *)(desc + (int64_t)(it.q_start + (qi < it.nq ? qi : 0)) * DP);
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) qf[cb][ks] = (qi < it.nq) ? p[4 * ks + g] : v4i{0, 0, 0, 0};
+        for (int ks = 0; ks < KS16; ks++) qf[cb][ks] = (qi < it.nq) ? p[4 * ks + g] : v4i{0, 0, 0, 0};
     }
     unsigned m[NCB][4], G[NCB];
 #pragma unroll
@@ -833,7 +861,7 @@ knn2_count16_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__
 #pragma clang diagnostic pop
     // LDS fragments of one unit (32 train rows = two 16-row tiles): A operands and the 4 cin values per tile
     struct Frag {
-        v4i a[2][2];
+        v4i a[2][KS16];
         v4i cv[2];
     };
     auto read_frag = [&](const unsigned char *base, int u, Frag &f) {
@@ -841,7 +869,7 @@ knn2_count16_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__
         for (int t = 0; t < 2; t++) {
             const int row = u * 32 + t * 16 + col;
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
+            for (int ks = 0; ks < KS16; ks++) {
                 const int slot = 4 * ks + g;
                 f.a[t][ks] = *(const v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4));
             }
@@ -851,10 +879,25 @@ knn2_count16_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__
     auto mfma_unit = [&](const Frag &f, v4i (&acc)[2][NCB]) {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
+            // K steps outermost: the four column blocks' chains are independent, so back-to-back issue never waits
 #pragma unroll
-            for (int cb = 0; cb < NCB; cb++) acc[t][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[t][0], qf[cb][0], f.cv[t], 0, 0, 0);
+            for (int ks = 0; ks < KS16; ks++) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; cb++) acc[t][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[t][1], qf[cb][1], acc[t][cb], 0, 0, 0);
+                for (int cb = 0; cb < NCB; cb++) {
+                    const v4i c_in = ks == 0 ? f.cv[t] : acc[t][cb];
+                    if constexpr (KIND == 0) {
+                        acc[t][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[t][ks], qf[cb][ks], c_in, 0, 0, 0);
+                    } else {
+                        // FP4 (E2M1) operands: 128 nibbles per instruction, the low 128 bits of the 256-bit operand;
+                        // cbsz = blgp = 4, scales 2^0
+                        const v4i &a = f.a[t][ks], &b = qf[cb][ks];
+                        const v4f r = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+                            v8i{a[0], a[1], a[2], a[3], 0, 0, 0, 0}, v8i{b[0], b[1], b[2], b[3], 0, 0, 0, 0},
+                            __builtin_bit_cast(v4f, c_in), 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                        acc[t][cb] = __builtin_bit_cast(v4i, r);
+                    }
+                }
+            }
         }
     };
     // fold one unit: per column block 4 streams take (x, y) = the two tiles' values (10 VALU ops per 8 distances)
@@ -939,7 +982,16 @@ knn2_count16_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__
         const bool mine = g == 0 && qi < it.nq;
         bool good = false, amb = false;
         int na = 0;
-        if (mine && H1 != 0u) {
+        if (KIND == 1) {
+            if (mine && H1 != 0u) {
+                good = true; // single-match row: kept unconditionally (stitcher.py:125-126)
+                if (H2 != 0u) {
+                    const float naf = (float)nrm[it.q_start + qi];
+                    const float d0 = naf - 2.f * (__uint_as_float(H1) - 512.f), d1 = naf - 2.f * (__uint_as_float(H2) - 512.f);
+                    good = (double)d0 < ratio * (double)d1; // Hamming distances as float32, ratio in float64
+                }
+            }
+        } else if (mine && H1 != 0u) {
             if (H2 == 0u) {
                 good = true; // single-match row: kept unconditionally (stitcher.py:125-126)
             } else {
@@ -951,8 +1003,8 @@ knn2_count16_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__
                 amb = (g_best != g_worst) || (flags & 1);
             }
         }
-        unsigned long long am = __ballot(amb);
-        while (am) {
+        unsigned long long am = KIND == 0 ? __ballot(amb) : 0ull;
+        while (KIND == 0 && am) {
             const int L = __ffsll((long long)am) - 1;
             am &= am - 1;
             int v1, v2;
@@ -984,7 +1036,9 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
         int32_t *co = count_out_dev + off;
         dim3 grid((unsigned)((n + 7) / 8 * 8 * nqb)), block(64 * ISX_COUNT_WAVES);
         if (d_pad == 128 && !(flags & 2))
-            hipLaunchKernelGGL(knn2_count16_kernel, grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
+            hipLaunchKernelGGL((knn2_count16_kernel<2>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
+        else if (d_pad == 64 && !(flags & 2))
+            hipLaunchKernelGGL((knn2_count16_kernel<1>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
         else if (d_pad == 128)
             hipLaunchKernelGGL((knn2_count_kernel<4>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
         else if (d_pad == 64)
@@ -1058,9 +1112,16 @@ extern "C" int isx_knn2_hamming_count_fp4(const uint8_t *desc_dev, const int32_t
     ISX_REQUIRE(per > 0, "max_nq too large (%d)", max_nq);
     for (int off = 0; off < n_items; off += per) {
         const int n = n_items - off < per ? n_items - off : per;
+#ifdef ISX_HAMMING_SHAPE16 /* experiment macro (tools/build_variant.sh): the 16x16x128 FP4 chain; measured 5.5 % SLOWER than
+                            the 32x32x64 one on 256-bit rows (profiles/r02_shape_ab.md), so it is not the default */
+        hipLaunchKernelGGL((knn2_count16_kernel<2, 1>), dim3((unsigned)((n + 7) / 8 * 8 * nqb)), dim3(64 * ISX_COUNT_WAVES), 0,
+                           (hipStream_t)stream, (const int8_t *)desc_dev, nrm_dev, cin_dev, items_dev + off, n, nqb, ratio,
+                           count_out_dev + off, 0);
+#else
         hipLaunchKernelGGL((knn2_count_kernel<4, 1>), dim3((unsigned)((n + 7) / 8 * 8 * nqb)), dim3(64 * ISX_COUNT_WAVES), 0,
                            (hipStream_t)stream, (const int8_t *)desc_dev, nrm_dev, cin_dev, items_dev + off, n, nqb, ratio,
                            count_out_dev + off, 0);
+#endif
     }
     return isx_launch_status("knn2_count_kernel<4,1>");
 }
