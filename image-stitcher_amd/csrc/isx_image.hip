@@ -25,7 +25,7 @@ __global__ void bbox_init_kernel(int32_t *bb) {
 // bounds and then queue ~10^4 atomics on one cache line -- measured +50 us on a 13 us warp.)  The table
 // is CALLER-OWNED: it is the tail of the bbox accumulator (ints ISX_BBOX_HEAD .. ISX_BBOX_INTS of
 // include/isx.h), so calls on different accumulators may overlap freely on one GPU.  The one exception is
-// isx_bbox_nonzero_static at the end of this file, whose table is a library-owned static array.
+// isx_bbox_nonzero_static (isx_bbox_static.hip), whose table is a library-owned static array.
 #define ISX_BBOX_MAX_BLOCKS ISX_BBOX_PARTIAL_BLOCKS
 
 // EVERY thread of a 256-thread block must call it

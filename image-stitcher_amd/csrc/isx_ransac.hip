@@ -3,8 +3,11 @@
 // for type 1).
 //
 // The sequential OpenCV loop (sample -> minimal solve -> count inliers -> adaptive stop) is split so
-// that everything data-parallel runs on the GPU and the result is IDENTICAL to running the loop in
-// order:
+// that everything data-parallel runs on the GPU while the SELECTION replays the loop in order (same
+// subsets, same "strictly better wins", same adaptive stop).  The arithmetic follows cv's to tolerance, not bit
+// for bit: the 4-point hypotheses are solved by Gauss-Jordan here (cv: eigenvector of LtL), so a point sitting on
+// the float32 threshold can change an inlier count.  tests/test_gpu_ransac.py gates the models to 1e-6 relative and
+// the inlier counts on the oracle's hypotheses; against cv2 itself this stage is "parity unpinned" (DESIGN.md 2):
 //   host   isx_ransac_sample      cv::RNG-faithful subset list (depends on the points only, never on
 //                                 the models, so all <=2000 subsets can be drawn up front)
 //   device isx_ransac_hypotheses  one lane per subset: 4-point DLT (normalised, null vector by

@@ -308,8 +308,10 @@ int isx_frame_download(isx_ctx *ctx, const uint8_t *src_dev, int64_t spitch, int
  *   type 0: cv2.estimateAffinePartial2D(src, dst)       (RANSAC thr 3.0, 2000 iters, conf 0.99, 10 LM iters)
  *   type 1: cv2.findHomography(src, dst, cv2.RANSAC, 5.0) (2000 iters, conf 0.995, DLT refit + 10 LM iters)
  * Points are float32 (x, y) pairs, n of them (the (G,1,2) arrays of Stitcher.get_pts, stitcher.py:129-133).
- * The sequential cv loop is reproduced exactly by: sample (host) -> hypotheses (GPU) -> score (GPU) ->
- * select (host, replays the in-order "strictly better wins" + adaptive stop) -> refine (GPU).
+ * The sequential cv loop's CONTROL FLOW is replayed by: sample (host) -> hypotheses (GPU) -> score (GPU) ->
+ * select (host, the in-order "strictly better wins" + adaptive stop) -> refine (GPU).  The arithmetic follows cv's to
+ * tolerance (models within 1e-6 relative of the CPU oracle's, same inlier counts on the same hypotheses), not bit for
+ * bit: against cv2 itself this stage is "parity unpinned" (DESIGN.md section 2).
  * ------------------------------------------------------------------------------------------------ */
 
 /* HOST.  cv::RNG(-1)-faithful subset list: up to max_iters subsets of 4 (homography) or 2 (affine
