@@ -15,7 +15,7 @@ when the timed region starts.  The pair space is fixed and split over the ranks 
 "strong".
 
 The JSON line also carries:
-  roofline     -- the dominant kernel (knn2_count16_kernel) against the dense int8 MFMA peak, from the
+  roofline     -- the dominant kernel (knn2_count16w_kernel) against the dense int8 MFMA peak, from the
                   kernel duration measured live with HIP events around the launch;
   cpu_baseline -- the CPU oracle's port of cv2.BFMatcher().knnMatch(float32) + ratio loop, timed on
                   a bounded sample of the same pairs on this host (rank 0, N=1 only);
@@ -375,7 +375,7 @@ def main():
                        "components_correct": bool(ok)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                          "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic,
-                         "kernel": "knn2_count16_kernel", "kernel_ms": k_ms,
+                         "kernel": "knn2_count16w_kernel", "kernel_ms": k_ms,
                          "note": "int8 MFMA ops; algorithmic 2*Nq*Nt*D per unordered pair (the kernel executes 2x: one pass per direction)"},
         }
         line["step_breakdown"] = breakdown

@@ -1017,6 +1017,195 @@ knn2_count16_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__
     if (lane == 0 && good_cnt) atomicAdd(&count_out[item_i], good_cnt);
 }
 
+// ------------------------------------------------------------------------------------------------
+// knn2_count16w_kernel: the 16x16x64 count kernel with EIGHT query column blocks per wave (128 queries) and a unit of
+// ONE 16-row train tile.  Every A fragment read from LDS now feeds 8 matrix instructions instead of 4: half the LDS
+// fragment reads per MAC, which on this power-limited kernel is what separates it from its register-only ingredient
+// loop (profiles/r02_bidir_probe.md: 142 ns against 185 ns per unit).  The fold pairs accumulator registers (0,2) and
+// (1,3) of the SAME tile -- two streams per column block instead of four -- so it still costs 5 three-input ops per
+// 4 distances.  190 VGPRs: 2 waves/SIMD.  Same staging, LDS layout and epilogue as knn2_count16_kernel<2, 0>.
+// Measured -5.4 to -6.0 % per launch against it (tools/count16_ab.py; 8 waves per workgroup instead of 4: +4 %, dropped).
+// ------------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 8 / WAVES)
+knn2_count16w_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm, const int32_t *__restrict__ cin,
+                     const isx_knn_item *__restrict__ items, int n_items, int nqb, double ratio,
+                     int32_t *__restrict__ count_out, int flags) {
+    constexpr int DP = 128, SLOTS = 8, SH = 1, CHUNK = 128;
+    constexpr int BUF = CHUNK * DP + CHUNK * 4;
+    __shared__ __align__(16) unsigned char smem[3 * BUF];
+
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int k = id >> 3;
+    const int qb = k % nqb;
+    const int item_i = (k / nqb) * 8 + xcd;
+    if (item_i >= n_items) return;
+    const isx_knn_item it = items[item_i];
+    constexpr int NCB = 8;
+    constexpr int QPW = 16 * NCB, QPB = WAVES * QPW;
+    if (qb * QPB >= it.nq) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, col = lane & 15;
+    const int q0 = qb * QPB + wave * QPW;
+    const int nt = it.nt;
+    const bool wave_live = q0 < it.nq;
+
+    v4i qf[NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        const int qi = q0 + cb * 16 + col;
+        const v4i *p = (const v4i *)(desc + (int64_t)(it.q_start + (qi < it.nq ? qi : 0)) * DP);
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) qf[cb][ks] = (qi < it.nq) ? p[4 * ks + g] : v4i{0, 0, 0, 0};
+    }
+    unsigned m[NCB][2], G[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) G[cb] = m[cb][0] = m[cb][1] = 0u;
+    const int n_chunks = (nt + CHUNK - 1) / CHUNK;
+
+    const __amdgpu_buffer_rsrc_t rs_desc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(desc + (int64_t)it.t_start * DP), 0, nt * DP, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cin =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(cin + it.t_start), 0, nt * 4, 0x00020000);
+    constexpr int ROWS_PP = 1024 / DP;
+    constexpr int PIECES = CHUNK * DP / 1024;
+    constexpr int PPW = (PIECES + WAVES - 1) / WAVES;
+    const int r_in = lane / SLOTS;
+    const int lane_voff = r_in * DP + (((lane % SLOTS) ^ (((wave * ROWS_PP + r_in) >> SH) & (SLOTS - 1))) << 4);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const unsigned smem_lds = (unsigned)(size_t)smem;
+    auto stage_chunk = [&](int c, int bufi) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int k = 0; k < PPW; k++) {
+            const int piece = wv + WAVES * k;
+            if (PIECES % WAVES != 0 && piece >= PIECES) break;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_desc, (lds_ptr_t)(smem_lds + bufi * BUF + piece * 1024), 16, lane_voff,
+                                                     c * (CHUNK * DP) + piece * 1024, 0, 0);
+        }
+        if (wv < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cin, (lds_ptr_t)(smem_lds + bufi * BUF + CHUNK * DP + wv * 256), 4,
+                                                     lane * 4, c * (CHUNK * 4) + wv * 256, 0, 0);
+    };
+#pragma clang diagnostic pop
+    struct Frag { // one 16-row tile: the A operand (2 K steps) and this lane's 4 cin values
+        v4i a[2];
+        v4i cv;
+    };
+    auto read_frag = [&](const unsigned char *base, int t, Frag &f) {
+        const int row = t * 16 + col;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int slot = 4 * ks + g;
+            f.a[ks] = *(const v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4));
+        }
+        f.cv = *(const v4i *)(base + CHUNK * DP + (t * 16 + 4 * g) * 4);
+    };
+    auto mfma_unit = [&](const Frag &f, v4i (&acc)[NCB]) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[0], qf[cb][0], f.cv, 0, 0, 0);
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[1], qf[cb][1], acc[cb], 0, 0, 0);
+    };
+    auto fold_unit = [&](const v4i (&acc)[NCB]) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            unsigned x0 = (unsigned)acc[cb][0], y0 = (unsigned)acc[cb][2];
+            unsigned x1 = (unsigned)acc[cb][1], y1 = (unsigned)acc[cb][3];
+            const unsigned t0 = umed3(m[cb][0], x0, y0);
+            const unsigned t1 = umed3(m[cb][1], x1, y1);
+            asm("" : "+v"(x0));
+            asm("" : "+v"(x1));
+            m[cb][0] = umax3(x0, y0, m[cb][0]);
+            m[cb][1] = umax3(x1, y1, m[cb][1]);
+            G[cb] = umax3(t0, t1, G[cb]);
+        }
+    };
+
+    if (n_chunks > 0) stage_chunk(0, 0);
+    if (n_chunks > 1) stage_chunk(1, 1);
+    __syncthreads();
+
+    v4i accA[NCB], accB[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) accB[cb] = v4i{0, 0, 0, 0};
+    Frag f0, f1;
+    if (wave_live) read_frag(smem, 0, f0);
+    int buf = 0;
+    for (int c = 0; c < n_chunks; c++) {
+        const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
+        if (c + 2 < n_chunks) stage_chunk(c + 2, buf2);
+        const unsigned char *base = smem + buf * BUF;
+        if (wave_live) {
+#pragma unroll
+            for (int t = 0; t < 8; t += 2) {
+                read_frag(base, t + 1, f1);
+                mfma_unit(f0, accA);
+                fold_unit(accB);
+                ISX_STEP_FENCE;
+                if (t + 2 < 8)
+                    read_frag(base, t + 2, f0);
+                else
+                    read_frag(smem + buf1 * BUF, 0, f0); // published by the previous barrier (unused after the last chunk)
+                mfma_unit(f1, accB);
+                fold_unit(accA);
+                ISX_STEP_FENCE;
+            }
+        }
+        __syncthreads();
+        buf = buf1;
+    }
+    if (!wave_live) return;
+    fold_unit(accB);
+
+    int good_cnt = 0;
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        unsigned b1 = m[cb][0] > m[cb][1] ? m[cb][0] : m[cb][1];
+        unsigned b2 = m[cb][0] > m[cb][1] ? m[cb][1] : m[cb][0];
+        b2 = b2 > G[cb] ? b2 : G[cb];
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) { // the four lanes (col, g) of a query
+            const unsigned o1 = __shfl_xor(b1, sh), o2 = __shfl_xor(b2, sh);
+            const unsigned mn = b1 > o1 ? o1 : b1, mx2 = b2 > o2 ? b2 : o2;
+            b1 = b1 > o1 ? b1 : o1;
+            b2 = mn > mx2 ? mn : mx2;
+        }
+        const unsigned H1 = b1, H2 = b2;
+        const int qi = q0 + cb * 16 + col;
+        const bool mine = g == 0 && qi < it.nq;
+        bool good = false, amb = false;
+        int na = 0;
+        if (mine && H1 != 0u) {
+            if (H2 == 0u) {
+                good = true; // single-match row: kept unconditionally (stitcher.py:125-126)
+            } else {
+                na = nrm[it.q_start + qi];
+                const int s0_hi = na - 2 * ((int)H1 - ISX_B2), s1_hi = na - 2 * ((int)H2 - ISX_B2);
+                const int s0_lo = s0_hi > 0 ? s0_hi - 1 : 0, s1_lo = s1_hi > 0 ? s1_hi - 1 : 0;
+                const bool g_best = ratio_good(s0_lo, s1_hi, ratio), g_worst = ratio_good(s0_hi, s1_lo, ratio);
+                good = g_best;
+                amb = (g_best != g_worst) || (flags & 1);
+            }
+        }
+        unsigned long long am = __ballot(amb);
+        while (am) {
+            const int L = __ffsll((long long)am) - 1;
+            am &= am - 1;
+            int v1, v2;
+            knn2_exact_scan<DP>(desc, nrm, it.q_start + __shfl(qi, L), it.t_start, nt, lane, v1, v2);
+            const int nal = __shfl(na, L);
+            if (lane == L) good = ratio_good(nal - v1, nal - v2, ratio);
+        }
+        good_cnt += __popcll(__ballot(good));
+    }
+    if (lane == 0 && good_cnt) atomicAdd(&count_out[item_i], good_cnt);
+}
+
 extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev,
                                        int d_pad, const isx_knn_item *items_dev, int n_items, int max_nq,
                                        double ratio, int32_t *count_out_dev, int flags, void *stream) {
@@ -1025,7 +1214,10 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
     if (n_items == 0 || max_nq == 0) return ISX_OK;
     ISX_REQUIRE(desc_dev && nrm_dev && cin_dev && items_dev && count_out_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
-    const int qpb = 32 * ISX_COUNT_WAVES * ISX_COUNT_NCB; // queries per workgroup
+    // 128-byte rows run on knn2_count16w_kernel (128 queries per wave); flags bit 2 selects its predecessor
+    // knn2_count16_kernel<2> (64 queries per wave), bit 1 the 32x32x32 kernel: the A/B references
+    const bool wide = d_pad == 128 && !(flags & 6);
+    const int qpb = wide ? 16 * 8 * ISX_COUNT_WAVES : 32 * ISX_COUNT_WAVES * ISX_COUNT_NCB; // queries per workgroup
     const int nqb = (max_nq + qpb - 1) / qpb;
     const int per = isx_items_per_launch(nqb, 64 * ISX_COUNT_WAVES);
     ISX_REQUIRE(per > 0, "max_nq too large (%d)", max_nq);
@@ -1035,7 +1227,9 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
         const isx_knn_item *it = items_dev + off;
         int32_t *co = count_out_dev + off;
         dim3 grid((unsigned)((n + 7) / 8 * 8 * nqb)), block(64 * ISX_COUNT_WAVES);
-        if (d_pad == 128 && !(flags & 2))
+        if (wide)
+            hipLaunchKernelGGL((knn2_count16w_kernel<ISX_COUNT_WAVES>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
+        else if (d_pad == 128 && !(flags & 2))
             hipLaunchKernelGGL((knn2_count16_kernel<2>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
         else if (d_pad == 64 && !(flags & 2))
             hipLaunchKernelGGL((knn2_count16_kernel<1>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);

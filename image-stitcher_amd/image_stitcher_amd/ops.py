@@ -203,7 +203,7 @@ def knn2_l2_items(P, items, ratio, want_matches=False, xcd_order=True, plan=None
             check(L.isx_knn2_l2_items(_ptr(P.desc), _ptr(P.cbase), _ptr(P.nrm), P.d_pad, _ptr(items_dev), m,
                                       max_nq, float(ratio), _ptr(idx), _ptr(dist), _ptr(out_dev),
                                       _ptr(counts), _stream()))
-        else:  # count-only kernel (verify_all: the test-hook `flags` of isx_knn2_l2_count_items, bits 0 and 1)
+        else:  # count-only kernel (verify_all: the test-hook `flags` of isx_knn2_l2_count_items, bits 0 to 2)
             check(L.isx_knn2_l2_count_items(_ptr(P.desc), _ptr(P.nrm), _ptr(P.cin), P.d_pad, _ptr(items_dev), m, max_nq,
                                             float(ratio), _ptr(counts), int(verify_all), _stream()))
         if events is not None:

@@ -102,8 +102,9 @@ int isx_knn2_l2_items(const int8_t *desc_dev, const uint32_t *cbase_dev, const i
  * as isx_knn2_l2_items; it skips the train indices, which more than halves the per-distance vector work.
  *   count_out_dev : int32 per item, MUST be zeroed by the caller
  *   flags         : bit 0 = decide EVERY query by the exact per-query scan (test hook, slow);
- *                   bit 1 = run 128-byte rows on the 32x32x32 MFMA kernel instead of the (faster) 16x16x64 one
- *                   (A/B hook: both give the same counts); other bits 0 */
+ *                   bit 1 = run 128- and 64-byte rows on the 32x32x32 MFMA kernel instead of the (faster) 16x16x64 ones;
+ *                   bit 2 = run 128-byte rows on the 16x16x64 kernel with 64 queries per wave instead of the (faster)
+ *                   one with 128 (A/B hooks: all give the same counts); other bits 0 */
 int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev, int d_pad,
                             const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
                             int32_t *count_out_dev, int flags, void *stream);

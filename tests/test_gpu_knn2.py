@@ -121,11 +121,14 @@ def _count_case(orc, des_list, ratio, verify_all):
                       for i in range(n) for j in range(n) if i != j and P.counts[i] and P.counts[j]], np.int32)
     pairs = [(i, j) for i in range(n) for j in range(n) if i != j and P.counts[i] and P.counts[j]]
     c = ops.knn2_l2_items(P, items, ratio, verify_all=verify_all)
-    # flags bit 1: 128-byte rows on the 32x32x32 MFMA kernel instead of the default 16x16x64 one
+    # flags bit 1: 128- / 64-byte rows on the 32x32x32 MFMA kernel; bit 2: 128-byte rows on the 16x16x64 kernel with 64
+    # queries per wave (the default has 128): the A/B references must give the same counts
     c_alt = ops.knn2_l2_items(P, items, ratio, verify_all=int(verify_all) ^ 2)
+    c_alt4 = ops.knn2_l2_items(P, items, ratio, verify_all=int(verify_all) ^ 4)
     c_idx, _ = ops.knn2_l2_items(P, items, ratio, want_matches=True)
     torch.cuda.synchronize()
     c, c_alt, c_idx = c.cpu().numpy(), c_alt.cpu().numpy(), c_idx.cpu().numpy()
+    assert np.array_equal(c_alt4.cpu().numpy(), c), "the two 16x16x64 count kernels differ"
     exp = np.array([orc.match_count(des_list[i], des_list[j], ratio) for i, j in pairs], np.int32)
     assert np.array_equal(c_idx, exp)
     assert np.array_equal(c, exp), f"count kernel differs on {np.nonzero(c != exp)[0][:10]}"
