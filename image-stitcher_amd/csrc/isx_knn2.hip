@@ -1138,25 +1138,25 @@ knn2_count16w_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict_
     int buf = 0;
     for (int c = 0; c < n_chunks; c++) {
         const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
-        if (c + 2 < n_chunks) stage_chunk(c + 2, buf2);
+        if (c + 2 < n_chunks && !(ISX_KNN_DIAG & 1)) stage_chunk(c + 2, buf2);
         const unsigned char *base = smem + buf * BUF;
         if (wave_live) {
 #pragma unroll
             for (int t = 0; t < 8; t += 2) {
                 read_frag(base, t + 1, f1);
                 mfma_unit(f0, accA);
-                fold_unit(accB);
+                if (!(ISX_KNN_DIAG & 8)) fold_unit(accB);
                 ISX_STEP_FENCE;
                 if (t + 2 < 8)
                     read_frag(base, t + 2, f0);
                 else
                     read_frag(smem + buf1 * BUF, 0, f0); // published by the previous barrier (unused after the last chunk)
                 mfma_unit(f1, accB);
-                fold_unit(accA);
+                if (!(ISX_KNN_DIAG & 8)) fold_unit(accA);
                 ISX_STEP_FENCE;
             }
         }
-        __syncthreads();
+        if (!(ISX_KNN_DIAG & 4)) __syncthreads();
         buf = buf1;
     }
     if (!wave_live) return;
