@@ -7,6 +7,10 @@ reference's cv2 SIFT/ORB so both paths see identical descriptors"; reference sti
   NumpySiftLite             -> the same corners with a 4x4x8 gradient-histogram descriptor post-processed like
                                cv2.SIFT's (normalise, clip 0.2, renormalise, x512, round): 128-d float32 that is
                                INTEGER VALUED in [0,255], the property the exact int8 matcher relies on
+  HipOrb                    -> OPT-IN on-GPU detector of ORB's structure (FAST-9 + Harris ranking + intensity-centroid
+                               orientation + steered BRIEF, single scale; csrc/isx_orb.hip).  NOT cv2.ORB:
+                               different keypoints and bits, so mosaics differ from a cv2 run (parity unpinned by
+                               construction); it removes the CPU detector from the frame loop.
 Any object with detectAndCompute(image, mask) -> (keypoints, descriptors) can be passed to the stitchers
 as `detector=`; keypoints need a mutable `.pt` (x, y) like cv2.KeyPoint.
 """
@@ -133,3 +137,149 @@ class NumpySiftLite(NumpyOrbLite):
         des = np.clip(np.rint(hist * 512.0), 0, 255).astype(np.float32)
         kps = KeyPointList([KeyPoint(x, y, v) for x, y, v in zip(xs, ys, resp)], np.stack([xs, ys], 1).astype(np.float32))
         return kps, des
+
+
+class LazyKeyPoints(list):
+    """Keypoints of HipOrb: the coordinates live in `xy` ((n,2) float32), the KeyPoint objects are only built when
+    somebody indexes or iterates the list (the stitchers' default path never does)."""
+    __slots__ = ("xy", "response", "angle", "_n", "_built")
+
+    def __init__(self, xy, response, angle):
+        super().__init__()
+        self.xy, self.response, self.angle, self._n, self._built = xy, response, angle, len(xy), False
+
+    def _build(self):
+        if not self._built:
+            self._built = True
+            for (x, y), r, a in zip(self.xy.tolist(), self.response.tolist(), self.angle.tolist()):
+                kp = KeyPoint(x, y, r)
+                list.append(self, kp)
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        self._build()
+        return list.__iter__(self)
+
+    def __getitem__(self, i):
+        self._build()
+        return list.__getitem__(self, i)
+
+
+def orb_base_pattern(seed=11):
+    """256 test pairs (x1, y1, x2, y2): isotropic Gaussian, sigma = 31/5, clipped to the radius-13 disc (rotation and
+    rounding then stay inside the radius-15 patch)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pts = []
+    while len(pts) < 512:
+        p = np.rint(rng.normal(0, 31 / 5.0, 2))
+        if p[0] * p[0] + p[1] * p[1] <= 13 * 13:
+            pts.append(p)
+    return np.array(pts, np.int64).reshape(256, 4)
+
+
+def orb_rotated_patterns(seed=11):
+    """int8 [32][256][4]: the base pairs rotated by k * 11.25 degrees, rounded once here on the host."""
+    base = orb_base_pattern(seed).astype(np.float64)
+    out = np.zeros((32, 256, 4), np.int8)
+    for k in range(32):
+        c, s = np.cos(k * 2 * np.pi / 32), np.sin(k * 2 * np.pi / 32)
+        for j in (0, 2):
+            x, y = base[:, j], base[:, j + 1]
+            out[k, :, j] = np.rint(x * c - y * s)
+            out[k, :, j + 1] = np.rint(x * s + y * c)
+    return out
+
+
+class HipOrb:
+    """detectAndCompute on the GPU (see the module docstring).  Accepts a numpy image (uploaded), a uint8 torch tensor
+    or a DeviceImage that already lives in HBM (`accepts_device`: the stitchers then skip the download of the mosaic
+    region).  Returns (LazyKeyPoints, (n,32) uint8 ndarray) like cv2.ORB; `des_dev` of the last call stays on the device.
+    One instance serves one thread."""
+    accepts_device = True
+
+    def __init__(self, nfeatures=500, fast_threshold=20, clean=16, seed=11, device=None):
+        self.nfeatures, self.fast_threshold, self.clean = int(nfeatures), int(fast_threshold), int(clean)
+        self.device = device
+        self._pattern_host = orb_rotated_patterns(seed)
+        self._pattern = None
+        self._ws = self._tiles = self._tiles_host = self._out = self._out_host = self._sel = self._sel_host = None
+
+    def _ensure(self, dev, h, w):
+        import torch
+        from . import ops
+        if self._pattern is None or self._pattern.device != dev:
+            self._pattern = torch.from_numpy(self._pattern_host).to(dev)
+            self._ws = self._tiles = self._out = self._sel = None
+        need = ops.orb_workspace_bytes(h, w)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need + need // 4,), dtype=torch.uint8, device=dev)
+        nt = ((h + 31) // 32) * ((w + 31) // 32)
+        if self._tiles is None or self._tiles.numel() < nt * 129:
+            self._tiles = torch.empty((nt * 129 + nt * 16,), dtype=torch.int32, device=dev)
+            self._tiles_host = torch.empty((self._tiles.numel(),), dtype=torch.int32).pin_memory()
+        n = self.nfeatures
+        if self._out is None or self._out.numel() < n * 36:
+            # descriptors (n x 32 bytes) followed by the angle bins (n int32), one download
+            self._out = torch.empty((n * 36,), dtype=torch.uint8, device=dev)
+            self._out_host = torch.empty((n * 36,), dtype=torch.uint8).pin_memory()
+            self._sel = torch.empty((n,), dtype=torch.int32, device=dev)
+            self._sel_host = torch.empty((n,), dtype=torch.int32).pin_memory()
+        return nt
+
+    def detectAndCompute(self, image, mask=None):
+        import torch
+        from . import ops
+        from .device_image import DeviceImage
+        if isinstance(image, DeviceImage):
+            t = image.t
+        elif isinstance(image, torch.Tensor):
+            t = image
+        else:
+            a = np.ascontiguousarray(np.asarray(image))
+            if a.dtype != np.uint8:
+                a = a.astype(np.uint8)
+            dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+            t = torch.from_numpy(a).to(dev)
+        if not t.is_cuda:
+            raise ops.IsxError("HipOrb needs a HIP device (there is no CPU path)")
+        h, w = int(t.shape[0]), int(t.shape[1])
+        if h < 2 * ops.ORB_EDGE + 1 or w < 2 * ops.ORB_EDGE + 1:
+            return [], None
+        dev = t.device
+        with torch.cuda.device(dev):
+            nt = self._ensure(dev, h, w)
+            ops.orb_candidates(t, self._ws, self._tiles, self.fast_threshold, self.clean)
+            th = self._tiles_host[:nt * 129]
+            th.copy_(self._tiles[:nt * 129], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            th = th.numpy()
+            counts = th[:nt]
+            total = int(counts.sum())
+            if total == 0:
+                return [], None
+            live = np.arange(64, dtype=np.int32)[None, :] < counts[:, None]
+            pos = th[nt:nt * 65].reshape(nt, 64)[live]
+            key = th[nt * 65:nt * 129].reshape(nt, 64)[live].view(np.uint32)
+            idx = (pos >> 16).astype(np.uint64) * np.uint64(w) + (pos & 0xFFFF).astype(np.uint64)
+            rank = ((~key).astype(np.uint64) << np.uint64(32)) | idx
+            n = min(self.nfeatures, total)
+            order = np.argpartition(rank, n - 1)[:n] if n < total else np.arange(total)
+            order = order[np.argsort(rank[order], kind="stable")]
+            pos, key = pos[order], key[order]
+            self._sel_host[:n].copy_(torch.from_numpy(pos))
+            sel = self._sel[:n]
+            sel.copy_(self._sel_host[:n], non_blocking=True)
+            des_d = self._out[:n * 32].view(n, 32)
+            ang_d = self._out[n * 32:n * 36].view(torch.int32)
+            ops.orb_describe(self._ws, h, w, sel, self._pattern, des_d, ang_d)
+            oh = self._out_host[:n * 36]
+            oh.copy_(self._out[:n * 36], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            oh = oh.numpy()
+            des = oh[:n * 32].reshape(n, 32).copy()
+            ang = oh[n * 32:].view(np.int32).copy()
+        self.des_dev = des_d
+        xy = np.stack([pos & 0xFFFF, pos >> 16], 1).astype(np.float32)
+        return LazyKeyPoints(xy, key.view(np.float32), ang.astype(np.float32) * 11.25), des

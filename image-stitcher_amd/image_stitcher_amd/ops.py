@@ -683,6 +683,43 @@ def copy2d(src, dst):
 
 
 # ---------------------------------------------------------------------------------------------
+# on-GPU ORB-style detection (opt-in; SURVEY 8f-4, reference stitcher.py:92-100)
+# ---------------------------------------------------------------------------------------------
+ORB_TILE, ORB_SLOTS, ORB_EDGE = 32, 64, 16
+
+
+def orb_workspace_bytes(h, w):
+    n = int(_lib.lib().isx_orb_workspace_bytes(int(h), int(w)))
+    if n <= 0:
+        raise IsxError(f"orb: image size {w}x{h} out of range")
+    return n
+
+
+def orb_candidates(img, workspace, tiles, fast_threshold=20, clean=16):
+    """isx_orb_candidates: queue gray / blur / FAST + Harris / NMS for a device image.  `workspace` = uint8 device tensor
+    of at least orb_workspace_bytes(h, w); `tiles` = int32 device tensor of n_tiles * (1 + 2 * 64) ints laid out as
+    [counts | positions | keys].  Nothing is synchronised."""
+    p, h, w, c, pitch = _img_args(img, "image")
+    nt = ((h + ORB_TILE - 1) // ORB_TILE) * ((w + ORB_TILE - 1) // ORB_TILE)
+    if workspace.numel() < orb_workspace_bytes(h, w) or tiles.numel() < nt * (1 + 2 * ORB_SLOTS):
+        raise IsxError("orb: workspace or tile buffer too small")
+    base = tiles.data_ptr()
+    with torch.cuda.device(img.device):
+        check(_lib.lib().isx_orb_candidates(p, h, w, c, pitch, int(fast_threshold), int(clean), _ptr(workspace),
+                                            ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * nt),
+                                            ctypes.c_void_p(base + 4 * nt * (1 + ORB_SLOTS)), _stream()))
+    return nt
+
+
+def orb_describe(workspace, h, w, pos, pattern, des_out, ang_out):
+    """isx_orb_describe for n = len(pos) selected positions ((y << 16) | x, int32 device tensor)."""
+    n = int(pos.numel())
+    with torch.cuda.device(pos.device):
+        check(_lib.lib().isx_orb_describe(_ptr(workspace), int(h), int(w), _ptr(pos), n, _ptr(pattern), _ptr(des_out), _ptr(ang_out),
+                                          _stream()))
+
+
+# ---------------------------------------------------------------------------------------------
 # robust transform (Stitcher.get_transform, reference stitcher.py:135-141)
 # ---------------------------------------------------------------------------------------------
 # cv2 defaults of the two calls the reference makes

@@ -65,9 +65,10 @@ def orb_like_descriptors(seed=1235, n_images=8, kp=500, d=32, flips=8, overlap=0
 # ---------------------------------------------------------------------------------------------
 # image-level streams
 # ---------------------------------------------------------------------------------------------
-def procedural_world(seed=42, h=3072, w=6144, channels=3):
+def procedural_world(seed=42, h=3072, w=6144, channels=3, speckle=0):
     """Seeded texture: multi-octave value noise + random rectangles, uint8 BGR, every pixel >= 12 so
-    content is never "black" under the reference's gray > 10 / gray != 0 tests."""
+    content is never "black" under the reference's gray > 10 / gray != 0 tests.  speckle = small high-contrast
+    blobs per 1000 pixels (0 = none): the smooth texture alone has few FAST corners, photographs have thousands."""
     from scipy import ndimage
     rng = np.random.Generator(np.random.PCG64(seed))
     acc = np.zeros((h, w, channels), np.float32)
@@ -84,6 +85,14 @@ def procedural_world(seed=42, h=3072, w=6144, channels=3):
         y, x = rng.integers(0, h - 8), rng.integers(0, w - 8)
         hh, ww = rng.integers(4, 60, 2)
         img[y:y + hh, x:x + ww] = rng.integers(12, 256, channels)
+    if speckle:
+        rs = np.random.Generator(np.random.PCG64(seed + 1000))  # (its own stream: speckle=0 worlds are unchanged)
+        n = int(h * w * speckle / 1000)
+        ys, xs = rs.integers(0, h - 5, n), rs.integers(0, w - 5, n)
+        sz = rs.integers(2, 5, (n, 2))
+        delta = rs.choice([-1.0, 1.0], n) * rs.integers(40, 100, n)
+        for y, x, (hh, ww), dv in zip(ys, xs, sz, delta):
+            img[y:y + hh, x:x + ww] += dv
     img = np.clip(img, 12, 255).astype(np.uint8)
     return img if channels > 1 else img[..., 0]
 

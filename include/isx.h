@@ -305,6 +305,34 @@ int isx_frame_download(isx_ctx *ctx, const uint8_t *src_dev, int64_t spitch, int
                        int64_t out_row_bytes, int off_y, int64_t off_x, const uint8_t **host_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * On-GPU ORB-style feature detection.  Stands where the reference calls
+ * cv2.ORB_create().detectAndCompute (stitcher.py:92-100, :163, :193-194, :263), as an OPT-IN detector: it is not
+ * cv2.ORB (cv2's learned pattern, pyramid and float arithmetic cannot be restated without cv2 -- parity with cv2 is
+ * unpinned by construction); what it computes is defined in integer arithmetic by tests/np_orb.py and matched bit for
+ * bit: FAST-9 corners, Harris ranking (k = 1/25), radius-3 NMS, intensity-centroid orientation in 32 bins, 256 steered
+ * BRIEF bits on a 7x7-blurred image, single scale.
+ *
+ * isx_orb_workspace_bytes: device scratch the two calls below share for an h x w image (about 8.2 bytes per pixel;
+ *   0 if the size is out of range: h, w <= 32767).
+ * isx_orb_candidates: queues 4 kernels.  Outputs per 32 x 32 tile t (tiles row-major, ceil(w/32) per row):
+ *   tile_count[t] survivors of the non-maximum suppression, their positions tile_pos[t*64 + i] = (y << 16) | x and
+ *   ranking keys tile_key[t*64 + i] = bits of float32(Harris response) (order inside a tile is unspecified).
+ *   fast_threshold: FAST-9 threshold (cv2.ORB default 20); clean: a corner is dropped when a gray == 0 pixel lies within
+ *   `clean` pixels (0..16; 0 = off) -- keeps keypoints off the black padding of canvases and mosaics.
+ *   The caller picks the keypoints (the nfeatures largest keys, ties to the lower y*w + x) and passes them back:
+ * isx_orb_describe: one kernel; pos_dev[n] positions as above (must come from isx_orb_candidates on the same workspace
+ *   contents; others yield angle -1 and zero bits), pattern_dev int8 [32][256][4] = the (x1,y1,x2,y2) test pairs for
+ *   each orientation bin, |coordinate| <= 15.  Writes des_out_dev[n][32] (bit of pair 8j is bit 7 of byte j) and
+ *   angle_out_dev[n] (bin 0..31 of 11.25 degrees).
+ * ------------------------------------------------------------------------------------------------ */
+int64_t isx_orb_workspace_bytes(int h, int w);
+int isx_orb_candidates(const uint8_t *img_dev, int h, int w, int c, int64_t pitch, int fast_threshold, int clean,
+                       void *workspace_dev, int32_t *tile_count_dev, int32_t *tile_pos_dev, uint32_t *tile_key_dev,
+                       void *stream);
+int isx_orb_describe(const void *workspace_dev, int h, int w, const int32_t *pos_dev, int n, const int8_t *pattern_dev,
+                     uint8_t *des_out_dev, int32_t *angle_out_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Robust transform.  Replaces Stitcher.get_transform (stitcher.py:135-141):
  *   type 0: cv2.estimateAffinePartial2D(src, dst)       (RANSAC thr 3.0, 2000 iters, conf 0.99, 10 LM iters)
  *   type 1: cv2.findHomography(src, dst, cv2.RANSAC, 5.0) (2000 iters, conf 0.995, DLT refit + 10 LM iters)
