@@ -11,7 +11,7 @@ def _declared():
     text = open(os.path.join(ROOT, "include", "isx.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"//[^\n]*", "", text)
-    return sorted(set(re.findall(r"^\s*(?:int|const char \*)\s*(isx_\w+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|int64_t|const char \*)\s*(isx_\w+)\s*\(", text, flags=re.M)))
 
 
 def test_header_symbols_are_exported():
