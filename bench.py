@@ -108,7 +108,7 @@ def stitch_workload(dev, n_frames):
     warm = 3
     k = len(frames) - warm
 
-    def stream(detector, **kw):
+    def stream(detector, frames=frames, **kw):
         st = ConsecutiveStitcher(log_level=3, output_dir=tempfile.mkdtemp(prefix="isx_bench_"), algorithm=1,
                                  consecutive_range=2, detector=detector, **kw)
         for f in frames[:warm]:
@@ -137,6 +137,20 @@ def stitch_workload(dev, n_frames):
     same_rp = bool(torch.equal(st.refs[-1].t, st_rp.refs[-1].t))
     replay_phases = dict(st_rp.phase_seconds)
     det.seconds, det.calls = live["seconds"], live["calls"]
+    # the opt-in on-GPU detector (detect.HipOrb): no CPU detector in the loop at all.  It is not cv2.ORB
+    # (different keypoints), and FAST corners need a texture with corners: the same path over the same world with
+    # small high-contrast blobs added (synthetic.procedural_world(speckle=4)).
+    from image_stitcher_amd.detect import HipOrb
+    world_s = procedural_world(seed=42, h=2160, w=1920 + int(0.15 * 1920 * (n_frames + 4)) + 400, speckle=4)
+    frames_s, _ = crop_path(world_s, n_frames + 3, (1080, 1920), step_frac=0.15, max_rot_deg=1.0, seed=43)
+    hip_det = HipOrb(nfeatures=1500)
+    stream(hip_det, frames=frames_s)  # (first run: workspace allocation, arena growth)
+    st_g, ok_g, wall_g = stream(hip_det, frames=frames_s)
+    gpu_det = {"value": k / wall_g, "unit": "frames/s", "ms_per_frame": wall_g / k * 1e3, "stitched": int(ok_g), "frames": k,
+               "detector": "HipOrb(nfeatures=1500): FAST-9 + Harris + NMS + orientation + steered BRIEF on the GPU (opt-in, "
+                           "not cv2.ORB: parity with cv2 unpinned by construction)",
+               "phase_ms_per_frame": {n: v / k * 1e3 for n, v in st_g.phase_seconds.items()},
+               "final_mosaic_shape": [int(v) for v in st_g.refs[-1].shape]}
     # kernel-level roofline of warp + feather blend on one representative 1080p frame: the launches of ONE
     # isx_frame_blend call (frame_warp_kernel, frame_extent_kernel, frame_gradient_kernel), queued back to back
     # between two HIP events on the launch stream.  Algorithmic bytes = frame read + mosaic read + write inside
@@ -202,6 +216,7 @@ def stitch_workload(dev, n_frames):
         "phase_ms_per_frame": {n: v / k * 1e3 for n, v in live["phases"].items()},
         "phase_ms_per_frame_replayed": {n: v / k * 1e3 for n, v in replay_phases.items()},
         "parallel_detect": {"value": k / wall_par, "unit": "frames/s", "stitched": int(ok_par), "same_mosaic": same},
+        "gpu_detection": gpu_det,
         "cpu_baseline": {"value": 1.0 / cpu_frame_s, "unit": "frames/s excluding detection", "cores": 1, "kind": "port",
                          "sample": f"1 frame: pad + warp + gradient merge + 3 bboxes on the {Wc}x{Hc} canvas as the reference "
                                    f"does them (oracle/orc_image.c), {cpu_frame_s:.2f} s"},

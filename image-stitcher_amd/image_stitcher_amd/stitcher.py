@@ -207,7 +207,7 @@ class Stitcher:
         """(detectAndCompute(img_a), detectAndCompute(make_b())) -- img_a on a worker thread while this thread
         fetches and detects the second image when parallel_detect is set, one after the other otherwise."""
         det = self.algorithm_obj
-        if not self.parallel_detect:
+        if not self.parallel_detect or getattr(det, "accepts_device", False):  # (a GPU detector serves one thread)
             ra = det.detectAndCompute(img_a, None)
             return ra, det.detectAndCompute(make_b(), None)
         if self._pool is None:
@@ -396,6 +396,28 @@ class Stitcher:
             out[iy0 - y0:iy1 - y0, ix0 - x0:ix1 - x0] = np.asarray(src)
         return out
 
+    def _device_region(self, img, ox, oy, H, W, p1, p2):
+        """_host_region for a detector that works in HBM (detect.HipOrb: `accepts_device`): the same pixels as a
+        device tensor -- a view of the resident image when the region lies inside it, else zeros + one device copy."""
+        if not isinstance(img, DeviceImage):
+            return self._host_region(img, ox, oy, H, W, p1, p2)
+        x0, y0 = max(0, min(W, p1[0])), max(0, min(H, p1[1]))
+        x1, y1 = max(x0, min(W, p2[0])), max(y0, min(H, p2[1]))
+        ih, iw = img.shape[:2]
+        if x0 >= ox and y0 >= oy and x1 <= ox + iw and y1 <= oy + ih and x1 > x0 and y1 > y0:
+            return img.t[y0 - oy:y1 - oy, x0 - ox:x1 - ox]
+        out = torch.zeros((y1 - y0, x1 - x0) + tuple(img.t.shape[2:]), dtype=torch.uint8, device=img.t.device)
+        ix0, iy0, ix1, iy1 = max(x0, ox), max(y0, oy), min(x1, ox + iw), min(y1, oy + ih)
+        if ix1 > ix0 and iy1 > iy0:
+            out[iy0 - y0:iy1 - y0, ix0 - x0:ix1 - x0] = img.t[iy0 - oy:iy1 - oy, ix0 - ox:ix1 - ox]
+        return out
+
+    @staticmethod
+    def _device_canvas(img_t, H, W, ox, oy):
+        out = torch.zeros((H, W) + tuple(img_t.shape[2:]), dtype=torch.uint8, device=img_t.device)
+        out[oy:oy + img_t.shape[0], ox:ox + img_t.shape[1]] = img_t
+        return out
+
     def _quad_region(self, M, ox, oy, iw, ih, W, H, margin):
         """Conservative canvas rectangle that contains every non-zero pixel of the warped frame."""
         pts = np.array([[ox - 1, oy - 1, 1], [ox + iw, oy - 1, 1], [ox + iw, oy + ih, 1], [ox - 1, oy + ih, 1]], np.float64)
@@ -578,6 +600,8 @@ class Stitcher:
 
         if tf is None:
             thisdes = None
+            dev_det = (getattr(self.algorithm_obj, "accepts_device", False) and isinstance(ref_d, DeviceImage)
+                       and not self._overridden("detectAndComputeFromCorners"))
             if corners is not None and self.consecutive_range is not None:
                 try:
                     if self._overridden("detectAndComputeFromCorners"):
@@ -586,9 +610,11 @@ class Stitcher:
                         thiskp, thisdes = self.detectAndComputeFromCorners(cur_c, current_corners)
                         refkp, refdes = self.detectAndComputeFromCorners(ref_c, corners)
                     else:
-                        cur_roi = self._host_region(img_d, ox, oy, H, W, current_corners[0], current_corners[1])
+                        # a detector that works in HBM gets device views: the mosaic region never visits the host
+                        region = self._device_region if dev_det else self._host_region
+                        cur_roi = region(img_d, ox, oy, H, W, current_corners[0], current_corners[1])
                         (kps, thisdes), (rkps, refdes) = self._detect_two(
-                            cur_roi, lambda: self._host_region(ref_d, rox, roy, H, W, corners[0], corners[1]))
+                            cur_roi, lambda: region(ref_d, rox, roy, H, W, corners[0], corners[1]))
                         if self._seams_plain:
                             # coordinates only (the keypoint objects do not leave this call): no per-object loops
                             thiskp, refkp = _kp_shifted(kps, current_corners[0]), _kp_shifted(rkps, corners[0])
@@ -599,8 +625,13 @@ class Stitcher:
                     self.logger.warning("Error in detecting keypoints from corners. Computing on whole image. Exception: ", str(e))
                     corners = None
             if corners is None or self.consecutive_range is None or thisdes is None:
-                (thiskp, thisdes), (refkp, refdes) = self._detect_two(
-                    self._host_canvas(img_d.numpy(), H, W, ox, oy), lambda: self._host_canvas(ref_d.numpy(), H, W, rox, roy))
+                if dev_det:
+                    with torch.cuda.device(dev):
+                        (thiskp, thisdes), (refkp, refdes) = self._detect_two(
+                            self._device_canvas(img_d.t, H, W, ox, oy), lambda: self._device_canvas(ref_d.t, H, W, rox, roy))
+                else:
+                    (thiskp, thisdes), (refkp, refdes) = self._detect_two(
+                        self._host_canvas(img_d.numpy(), H, W, ox, oy), lambda: self._host_canvas(ref_d.numpy(), H, W, rox, roy))
 
             tp = self._phase("detect(cpu)+roi_download+kp", tp)
             if refdes is None:
