@@ -28,8 +28,9 @@
 #define ORB_HALO 4    // FAST radius 3, Harris radius 3 + 1
 #define ORB_MAX_CORNERS 1024
 
-__constant__ int c_orb_circle[16][2] = {{0, -3}, {1, -3}, {2, -2}, {3, -1}, {3, 0},  {3, 1},   {2, 2},   {1, 3},
-                                        {0, 3},  {-1, 3}, {-2, 2}, {-3, 1}, {-3, 0}, {-3, -1}, {-2, -2}, {-1, -3}};
+// (constexpr, not __constant__: with the loop unrolled the offsets fold into the LDS instructions' immediates)
+static constexpr int c_orb_circle[16][2] = {{0, -3}, {1, -3}, {2, -2}, {3, -1}, {3, 0},  {3, 1},   {2, 2},   {1, 3},
+                                            {0, 3},  {-1, 3}, {-2, 2}, {-3, 1}, {-3, 0}, {-3, -1}, {-2, -2}, {-1, -3}};
 __constant__ int c_orb_dirs[32][2] = {
     {16384, 0},      {16069, 3196},    {15137, 6270},    {13623, 9102},    {11585, 11585},   {9102, 13623},   {6270, 15137},
     {3196, 16069},   {0, 16384},       {-3196, 16069},   {-6270, 15137},   {-9102, 13623},   {-11585, 11585}, {-13623, 9102},
@@ -134,16 +135,37 @@ __device__ __forceinline__ bool orb_row_has_zero(const uint64_t *__restrict__ ro
 __global__ void __launch_bounds__(256) orb_fast_harris_kernel(const uint8_t *__restrict__ g, int h, int w, int thr, int clean,
                                                               const uint64_t *__restrict__ zb, int zw,
                                                               uint32_t *__restrict__ key) {
-    __shared__ uint8_t t[ORB_TH + 2 * ORB_HALO][ORB_TW + 2 * ORB_HALO];
+    __shared__ __align__(16) uint8_t t[ORB_TH + 2 * ORB_HALO][ORB_TW + 2 * ORB_HALO];
     __shared__ int corners[ORB_MAX_CORNERS];
     __shared__ int n_corners;
+    // the bit rows (gray == 0) every `clean` window of this tile can touch: rows Y0-16 .. Y0+31, three 64-column words
+    // around the tile's own (X0 is a multiple of 64) -- staged once, so scoring a corner waits on no global load
+    __shared__ uint64_t zt[ORB_TH + 2 * ORB_E][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int X0 = blockIdx.x * ORB_TW, Y0 = blockIdx.y * ORB_TH;
     if (tid == 0) n_corners = 0;
-    for (int p = tid; p < (ORB_TH + 2 * ORB_HALO) * (ORB_TW + 2 * ORB_HALO); p += 256) {
-        const int ly = p / (ORB_TW + 2 * ORB_HALO), lx = p % (ORB_TW + 2 * ORB_HALO);
-        const int yy = min(max(Y0 + ly - ORB_HALO, 0), h - 1), xx = min(max(X0 + lx - ORB_HALO, 0), w - 1);
-        t[ly][lx] = g[(int64_t)yy * w + xx];
+    if (tid < (ORB_TH + 2 * ORB_E) * 3) {
+        const int r = tid / 3, k = tid % 3, yy = Y0 - ORB_E + r, wd = (X0 >> 6) - 1 + k;
+        zt[r][k] = (yy >= 0 && yy < h && wd >= 0 && wd < zw) ? zb[(int64_t)yy * zw + wd] : 0ull;
+    }
+    constexpr int TWH = ORB_TW + 2 * ORB_HALO, THH = ORB_TH + 2 * ORB_HALO;
+    if (X0 >= ORB_HALO && X0 + ORB_TW + ORB_HALO <= w && Y0 >= ORB_HALO && Y0 + ORB_TH + ORB_HALO <= h) {
+        // interior tile: 18 unaligned dword loads per row, both rounds in flight together (the byte-wise loop below
+        // serialises seven memory round trips per workgroup and set the kernel's time)
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int q = tid + 256 * it;
+            if (q < THH * (TWH / 4)) {
+                const int ly = q / (TWH / 4), c4 = q % (TWH / 4);
+                *(uint32_t *)&t[ly][4 * c4] = *(const u32u *)(g + (int64_t)(Y0 - ORB_HALO + ly) * w + (X0 - ORB_HALO + 4 * c4));
+            }
+        }
+    } else {
+        for (int p = tid; p < THH * TWH; p += 256) {
+            const int ly = p / TWH, lx = p % TWH;
+            const int yy = min(max(Y0 + ly - ORB_HALO, 0), h - 1), xx = min(max(X0 + lx - ORB_HALO, 0), w - 1);
+            t[ly][lx] = g[(int64_t)yy * w + xx];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -182,8 +204,8 @@ __global__ void __launch_bounds__(256) orb_fast_harris_kernel(const uint8_t *__r
         }
         bool dirty = false;
         if (clean > 0 && lane <= 2 * clean) {
-            const int yy = Y - clean + lane; // ORB_E >= clean: the window lies inside the image
-            dirty = orb_row_has_zero(zb + (int64_t)yy * zw, zw, X - clean, X + clean);
+            // ORB_E >= clean: the window lies inside the image, and inside the staged rows / words
+            dirty = orb_row_has_zero(zt[ly + ORB_E - clean + lane], 3, lx + 64 - clean, lx + 64 + clean);
         }
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) { // (products up to 1020^2: the three sums fit 32 bits, kept as int for the shuffles)
@@ -243,9 +265,11 @@ __global__ void __launch_bounds__(256) orb_nms_kernel(const uint32_t *__restrict
 
 // K5: grid n, block 64
 __global__ void __launch_bounds__(64) orb_describe_kernel(const uint8_t *__restrict__ g, const uint8_t *__restrict__ bl, int h, int w,
-                                                          const int32_t *__restrict__ pos, const int8_t *__restrict__ pattern,
+                                                          const int32_t *__restrict__ pos, const int32_t *__restrict__ n_dev,
+                                                          const int8_t *__restrict__ pattern,
                                                           uint8_t *__restrict__ des, int32_t *__restrict__ ang) {
     const int kp = blockIdx.x, lane = threadIdx.x;
+    if (n_dev && kp >= n_dev[0]) return; // (the count of a device-side selection: the grid was sized for nfeatures)
     const int pk = pos[kp], X = pk & 0xFFFF, Y = pk >> 16;
     if (X < ORB_E || X >= w - ORB_E || Y < ORB_E || Y >= h - ORB_E) { // not a position K4 can have produced: touch nothing outside
         if (lane < 32) des[(int64_t)kp * 32 + lane] = 0;
@@ -330,7 +354,120 @@ extern "C" int isx_orb_describe(const void *workspace_dev, int h, int w, const i
     if (n == 0) return ISX_OK;
     ISX_REQUIRE(workspace_dev && pos_dev && pattern_dev && des_out_dev && angle_out_dev, "null device pointer");
     const OrbWs s = orb_ws((void *)workspace_dev, h, w);
-    hipLaunchKernelGGL(orb_describe_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, s.g, s.bl, h, w, pos_dev, pattern_dev,
-                       des_out_dev, angle_out_dev);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, s.g, s.bl, h, w, pos_dev,
+                       (const int32_t *)nullptr, pattern_dev, des_out_dev, angle_out_dev);
     return isx_launch_status("orb_describe_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Selection on the device: the nfeatures best NMS survivors (largest key, ties to the lower linear index) in order.
+//   S1 orb_gather_kernel  prefix sum of the tile counts (a workgroup per 64 tiles; each sums the counts before its own),
+//                         the sparse tile slots packed into a dense list of 64-bit ranks (~key << 32 | y*w + x), all
+//                         distinct (the list lives in the workspace's h-blur buffer, which is dead by now)
+//   S2 orb_rank_kernel    16 threads per survivor: its position in the sorted order = the number of ranks below its own
+//                         (the list streams through LDS in blocks of 1024); positions < nfeatures are written.  n^2
+//                         compares -- 4 x 10^7 for the ~6500 survivors of a 1080p frame -- spread over every CU; measured
+//                         alternatives: a one-workgroup bitonic sort in LDS 126 us (91 LDS-bound passes), one thread per
+//                         survivor 103 us (26 workgroups busy)
+// sel[0] = number selected (or -1: more than ORB_SELECT_CAP survivors, the caller selects on the host),
+// sel[1] = survivors in total, sel[2 ..] = positions ((y << 16) | x), then nfeatures keys.
+// ------------------------------------------------------------------------------------------------
+#define ORB_SELECT_CAP 65536
+// S1: grid = ceil(n_tiles / 64) workgroups of 256: workgroup b packs tiles [64b, 64b + 64)
+__global__ void __launch_bounds__(256) orb_gather_kernel(const int32_t *__restrict__ tile_count, const int32_t *__restrict__ tile_pos,
+                                                         const uint32_t *__restrict__ tile_key, int n_tiles, int w, int nfeatures,
+                                                         uint64_t *__restrict__ dense, int32_t *__restrict__ sel) {
+    __shared__ int wsum[4];
+    __shared__ int offs[64], cnts[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t_first = blockIdx.x * 64;
+    // survivors in the tiles before this workgroup's (every workgroup sums them itself: a few thousand ints from L2)
+    int before = 0;
+    for (int t = tid; t < t_first; t += 256) before += max(0, min(tile_count[t], ORB_SLOTS));
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) before += __shfl_xor(before, m);
+    if (lane == 0) wsum[wave] = before;
+    __syncthreads();
+    before = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (wave == 0) { // exclusive prefix over this workgroup's 64 tiles
+        const int t = t_first + lane;
+        const int c = t < n_tiles ? max(0, min(tile_count[t], ORB_SLOTS)) : 0;
+        int incl = c;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int o = __shfl_up(incl, m);
+            if (lane >= m) incl += o;
+        }
+        offs[lane] = before + incl - c;
+        cnts[lane] = c;
+        if (lane == 63 && t_first + 64 >= n_tiles) { // the last workgroup knows the total
+            const int total = before + incl;
+            sel[1] = total;
+            sel[0] = total > ORB_SELECT_CAP ? -1 : min(total, nfeatures);
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int sl = tid; sl < 64 * ORB_SLOTS; sl += 256) {
+        const int tl = sl >> 6, i = sl & 63;
+        if (i < cnts[tl] && offs[tl] + i < ORB_SELECT_CAP) {
+            const int t = t_first + tl;
+            const int p = tile_pos[t * ORB_SLOTS + i];
+            const uint32_t k = tile_key[t * ORB_SLOTS + i];
+            dense[offs[tl] + i] = ((uint64_t)(~k) << 32) | (uint32_t)((p >> 16) * w + (p & 0xFFFF));
+        }
+    }
+}
+
+// S2: grid = ceil(cap / 16) workgroups of 256: 16 survivors per workgroup, 16 threads per survivor (each compares
+// its survivor with every 16th entry of the list, which streams through LDS in blocks of 1024)
+__global__ void __launch_bounds__(256) orb_rank_kernel(const uint64_t *__restrict__ dense, int w, int nfeatures,
+                                                       int32_t *__restrict__ sel) {
+    __shared__ uint64_t blk[1024];
+    const int total = sel[1];
+    if (sel[0] < 0 || (int)blockIdx.x * 16 >= total) return; // (block-uniform)
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
+    const uint64_t mine = i < total ? dense[i] : 0ull;
+    int below = 0;
+    for (int b0 = 0; b0 < total; b0 += 1024) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < 1024; k += 256) blk[k] = b0 + k < total ? dense[b0 + k] : ~0ull;
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 64; k++) below += blk[16 * k + part] < mine;
+    }
+    below += __shfl_xor(below, 1);
+    below += __shfl_xor(below, 2);
+    below += __shfl_xor(below, 4);
+    below += __shfl_xor(below, 8);
+    if (part == 0 && i < total && below < nfeatures) {
+        const uint32_t idx = (uint32_t)mine;
+        sel[2 + below] = (int32_t)(((idx / (uint32_t)w) << 16) | (idx % (uint32_t)w));
+        sel[2 + nfeatures + below] = (int32_t)~(uint32_t)(mine >> 32);
+    }
+}
+
+extern "C" int isx_orb_select_describe(const void *workspace_dev, int h, int w, const int32_t *tile_count_dev,
+                                       const int32_t *tile_pos_dev, const uint32_t *tile_key_dev, int nfeatures,
+                                       const int8_t *pattern_dev, int32_t *sel_out_dev, uint8_t *des_out_dev,
+                                       int32_t *angle_out_dev, void *stream) {
+    ISX_REQUIRE(h > 0 && w > 0 && h <= 32767 && w <= 32767, "image size %dx%d out of range", w, h);
+    ISX_REQUIRE(nfeatures >= 1 && nfeatures <= ORB_SELECT_CAP, "nfeatures must be in [1, %d]", ORB_SELECT_CAP);
+    ISX_REQUIRE(h >= 2 * ORB_E + 1 && w >= 2 * ORB_E + 1, "image smaller than one patch (%dx%d)", w, h);
+    ISX_REQUIRE(workspace_dev && tile_count_dev && tile_pos_dev && tile_key_dev && pattern_dev && sel_out_dev && des_out_dev &&
+                    angle_out_dev,
+                "null device pointer");
+    const int n_tiles = ((h + ORB_TILE - 1) / ORB_TILE) * ((w + ORB_TILE - 1) / ORB_TILE);
+    const OrbWs s = orb_ws((void *)workspace_dev, h, w);
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t *dense = (uint64_t *)s.hs; // h*w*2 bytes >= n_tiles*64*8 for every admitted size; dead after the v-blur
+    const int64_t cap = (int64_t)n_tiles * ORB_SLOTS < ORB_SELECT_CAP ? (int64_t)n_tiles * ORB_SLOTS : ORB_SELECT_CAP;
+    ISX_REQUIRE((int64_t)h * w * 2 >= cap * 8, "image too small for the selection scratch"); // (h, w >= 33 always pass)
+    hipLaunchKernelGGL(orb_gather_kernel, dim3((n_tiles + 63) / 64), dim3(256), 0, st, tile_count_dev, tile_pos_dev, tile_key_dev,
+                       n_tiles, w, nfeatures, dense, sel_out_dev);
+    hipLaunchKernelGGL(orb_rank_kernel, dim3((unsigned)((cap + 15) / 16)), dim3(256), 0, st, (const uint64_t *)dense, w, nfeatures,
+                       sel_out_dev);
+    hipLaunchKernelGGL(orb_describe_kernel, dim3(nfeatures), dim3(64), 0, st, s.g, s.bl, h, w, (const int32_t *)(sel_out_dev + 2),
+                       (const int32_t *)sel_out_dev, pattern_dev, des_out_dev, angle_out_dev);
+    return isx_launch_status("orb_select_describe");
 }

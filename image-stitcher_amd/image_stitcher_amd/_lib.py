@@ -60,6 +60,8 @@ SIGNATURES = {
     "isx_orb_candidates": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),
     "isx_orb_describe": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "isx_orb_select_describe": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
     "isx_ctx_create": (c_int, [c_void_p]),
     "isx_ctx_destroy": (c_int, [c_void_p]),
     "isx_frame_blend": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_int,

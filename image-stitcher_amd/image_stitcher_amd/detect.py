@@ -199,8 +199,9 @@ class HipOrb:
     One instance serves one thread."""
     accepts_device = True
 
-    def __init__(self, nfeatures=500, fast_threshold=20, clean=16, seed=11, device=None):
+    def __init__(self, nfeatures=500, fast_threshold=20, clean=16, seed=11, device=None, device_select=True):
         self.nfeatures, self.fast_threshold, self.clean = int(nfeatures), int(fast_threshold), int(clean)
+        self.device_select = bool(device_select)  # False: pick the keypoints on the host (what happens beyond 65536 survivors)
         self.device = device
         self._pattern_host = orb_rotated_patterns(seed)
         self._pattern = None
@@ -220,10 +221,11 @@ class HipOrb:
             self._tiles = torch.empty((nt * 129 + nt * 16,), dtype=torch.int32, device=dev)
             self._tiles_host = torch.empty((self._tiles.numel(),), dtype=torch.int32).pin_memory()
         n = self.nfeatures
-        if self._out is None or self._out.numel() < n * 36:
-            # descriptors (n x 32 bytes) followed by the angle bins (n int32), one download
-            self._out = torch.empty((n * 36,), dtype=torch.uint8, device=dev)
-            self._out_host = torch.empty((n * 36,), dtype=torch.uint8).pin_memory()
+        if self._out is None:
+            # one block, one download: [sel: 2 + 2n int32 | angle bins: n int32 | descriptors: n x 32 bytes]
+            nbytes = (2 + 2 * n) * 4 + n * 4 + n * 32
+            self._out = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+            self._out_host = torch.empty((nbytes,), dtype=torch.uint8).pin_memory()
             self._sel = torch.empty((n,), dtype=torch.int32, device=dev)
             self._sel_host = torch.empty((n,), dtype=torch.int32).pin_memory()
         return nt
@@ -251,35 +253,58 @@ class HipOrb:
         with torch.cuda.device(dev):
             nt = self._ensure(dev, h, w)
             ops.orb_candidates(t, self._ws, self._tiles, self.fast_threshold, self.clean)
-            th = self._tiles_host[:nt * 129]
-            th.copy_(self._tiles[:nt * 129], non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            th = th.numpy()
-            counts = th[:nt]
-            total = int(counts.sum())
-            if total == 0:
+            N = self.nfeatures
+            o_sel, o_ang, o_des = 0, (2 + 2 * N) * 4, (2 + 2 * N) * 4 + N * 4
+            sel_d = self._out[o_sel:o_ang].view(torch.int32)
+            ang_d = self._out[o_ang:o_des].view(torch.int32)
+            des_d = self._out[o_des:o_des + N * 32].view(N, 32)
+            if self.device_select and N <= 65536:
+                # selection on the device: 6 kernels queued back to back, ONE download, one synchronisation
+                ops.orb_select_describe(self._ws, h, w, self._tiles, N, self._pattern, sel_d, des_d, ang_d)
+                self._out_host.copy_(self._out, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                oh = self._out_host.numpy()
+                head = oh[:o_ang].view(np.int32)
+                n = int(head[0])
+            else:
+                n = -1
+            if n == 0:
                 return [], None
-            live = np.arange(64, dtype=np.int32)[None, :] < counts[:, None]
-            pos = th[nt:nt * 65].reshape(nt, 64)[live]
-            key = th[nt * 65:nt * 129].reshape(nt, 64)[live].view(np.uint32)
-            idx = (pos >> 16).astype(np.uint64) * np.uint64(w) + (pos & 0xFFFF).astype(np.uint64)
-            rank = ((~key).astype(np.uint64) << np.uint64(32)) | idx
-            n = min(self.nfeatures, total)
-            order = np.argpartition(rank, n - 1)[:n] if n < total else np.arange(total)
-            order = order[np.argsort(rank[order], kind="stable")]
-            pos, key = pos[order], key[order]
-            self._sel_host[:n].copy_(torch.from_numpy(pos))
-            sel = self._sel[:n]
-            sel.copy_(self._sel_host[:n], non_blocking=True)
-            des_d = self._out[:n * 32].view(n, 32)
-            ang_d = self._out[n * 32:n * 36].view(torch.int32)
-            ops.orb_describe(self._ws, h, w, sel, self._pattern, des_d, ang_d)
-            oh = self._out_host[:n * 36]
-            oh.copy_(self._out[:n * 36], non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            oh = oh.numpy()
-            des = oh[:n * 32].reshape(n, 32).copy()
-            ang = oh[n * 32:].view(np.int32).copy()
+            if n > 0:
+                pos = head[2:2 + n].copy()
+                key = head[2 + N:2 + N + n].view(np.uint32).copy()
+                ang = oh[o_ang:o_ang + 4 * n].view(np.int32).copy()
+                des = oh[o_des:o_des + 32 * n].reshape(n, 32).copy()
+                des_d = des_d[:n]
+            else:
+                # more survivors than the device sort takes (or device_select off): select on the host from the tile slots
+                th = self._tiles_host[:nt * 129]
+                th.copy_(self._tiles[:nt * 129], non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                th = th.numpy()
+                counts = th[:nt]
+                total = int(counts.sum())
+                if total == 0:
+                    return [], None
+                live = np.arange(64, dtype=np.int32)[None, :] < counts[:, None]
+                pos = th[nt:nt * 65].reshape(nt, 64)[live]
+                key = th[nt * 65:nt * 129].reshape(nt, 64)[live].view(np.uint32)
+                idx = (pos >> 16).astype(np.uint64) * np.uint64(w) + (pos & 0xFFFF).astype(np.uint64)
+                rank = ((~key).astype(np.uint64) << np.uint64(32)) | idx
+                n = min(N, total)
+                order = np.argpartition(rank, n - 1)[:n] if n < total else np.arange(total)
+                order = order[np.argsort(rank[order], kind="stable")]
+                pos, key = pos[order], key[order]
+                self._sel_host[:n].copy_(torch.from_numpy(pos))
+                sel = self._sel[:n]
+                sel.copy_(self._sel_host[:n], non_blocking=True)
+                des_d, ang_n = des_d[:n], ang_d[:n]
+                ops.orb_describe(self._ws, h, w, sel, self._pattern, des_d, ang_n)
+                self._out_host.copy_(self._out, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                oh = self._out_host.numpy()
+                ang = oh[o_ang:o_ang + 4 * n].view(np.int32).copy()
+                des = oh[o_des:o_des + 32 * n].reshape(n, 32).copy()
         self.des_dev = des_d
         xy = np.stack([pos & 0xFFFF, pos >> 16], 1).astype(np.float32)
         return LazyKeyPoints(xy, key.view(np.float32), ang.astype(np.float32) * 11.25), des

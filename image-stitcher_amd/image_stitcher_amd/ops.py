@@ -711,6 +711,17 @@ def orb_candidates(img, workspace, tiles, fast_threshold=20, clean=16):
     return nt
 
 
+def orb_select_describe(workspace, h, w, tiles, nfeatures, pattern, sel_out, des_out, ang_out):
+    """isx_orb_select_describe: device-side selection of the nfeatures best survivors + their descriptors (2 kernels, no
+    synchronisation).  `tiles` as filled by orb_candidates; sel_out int32 [2 + 2*nfeatures]."""
+    nt = ((h + ORB_TILE - 1) // ORB_TILE) * ((w + ORB_TILE - 1) // ORB_TILE)
+    base = tiles.data_ptr()
+    with torch.cuda.device(tiles.device):
+        check(_lib.lib().isx_orb_select_describe(_ptr(workspace), int(h), int(w), ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * nt),
+                                                 ctypes.c_void_p(base + 4 * nt * (1 + ORB_SLOTS)), int(nfeatures), _ptr(pattern),
+                                                 _ptr(sel_out), _ptr(des_out), _ptr(ang_out), _stream()))
+
+
 def orb_describe(workspace, h, w, pos, pattern, des_out, ang_out):
     """isx_orb_describe for n = len(pos) selected positions ((y << 16) | x, int32 device tensor)."""
     n = int(pos.numel())

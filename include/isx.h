@@ -331,6 +331,17 @@ int isx_orb_candidates(const uint8_t *img_dev, int h, int w, int c, int64_t pitc
                        void *stream);
 int isx_orb_describe(const void *workspace_dev, int h, int w, const int32_t *pos_dev, int n, const int8_t *pattern_dev,
                      uint8_t *des_out_dev, int32_t *angle_out_dev, void *stream);
+/* The selection on the device followed by isx_orb_describe, without a host round trip in between (3 kernels).
+ * sel_out_dev: int32 [2 + 2*nfeatures] = {n selected, survivors in total, n positions ((y << 16) | x) in rank order
+ * padded to nfeatures, n keys padded to nfeatures}; des_out_dev [nfeatures][32] and angle_out_dev [nfeatures] are
+ * written for the first n.  n = -1 when there are more than 65536 survivors (the selection ranks by counting, n^2
+ * compares): the caller then selects on the host from the tile slots and calls isx_orb_describe.  nfeatures in
+ * [1, 65536]; h, w >= 33.  Overwrites the workspace's blur scratch (isx_orb_candidates must run again before the next
+ * isx_orb_select_describe; isx_orb_describe keeps working). */
+int isx_orb_select_describe(const void *workspace_dev, int h, int w, const int32_t *tile_count_dev,
+                            const int32_t *tile_pos_dev, const uint32_t *tile_key_dev, int nfeatures,
+                            const int8_t *pattern_dev, int32_t *sel_out_dev, uint8_t *des_out_dev, int32_t *angle_out_dev,
+                            void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Robust transform.  Replaces Stitcher.get_transform (stitcher.py:135-141):

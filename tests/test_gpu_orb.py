@@ -93,6 +93,23 @@ def test_black_regions_and_plateaus(cuda):
     tile[4:7, 4:7] = 200
     per = np.tile(tile, (20, 26))          # identical blobs: identical responses everywhere
     assert _check(HipOrb(nfeatures=50), per) == 50
+    assert _check(HipOrb(nfeatures=50, device_select=False), per) == 50      # the host-side selection, same answer
+
+
+def test_more_survivors_than_the_device_sort_takes(cuda):
+    """> 65536 NMS survivors: isx_orb_select_describe reports -1 and the keypoints are picked on the host from the tile
+    slots -- same definition, same result."""
+    from image_stitcher_amd.detect import HipOrb
+    rng = np.random.default_rng(5)
+    tile = np.full((8, 8), 60, np.uint8)
+    tile[2:5, 2:5] = 200
+    per = np.tile(tile, (268, 268)).astype(np.int16)
+    per += rng.integers(0, 3, per.shape, dtype=np.int16)   # break the ties so that the order is by response
+    per = per.astype(np.uint8)
+    det = HipOrb(nfeatures=300)
+    assert _check(det, per) == 300
+    nt = ((per.shape[0] + 31) // 32) * ((per.shape[1] + 31) // 32)
+    assert int(det._tiles_host[:nt].sum()) > 65536
 
 
 def test_full_hd_frame(cuda):
