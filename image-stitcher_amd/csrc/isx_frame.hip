@@ -332,7 +332,8 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
 __global__ void __launch_bounds__(1024) frame_extent_kernel(const int32_t *__restrict__ rows, int qx0, int qy0, int qw,
                                                             int qh, int canvas_w, int canvas_h, int margin,
                                                             const uint64_t *__restrict__ mask, int nchunk,
-                                                            int32_t *__restrict__ cols, int32_t *__restrict__ res) {
+                                                            int32_t *__restrict__ cols, int cstride,
+                                                            int32_t *__restrict__ res) {
     __shared__ uint64_t wm[FE_BATCH][4];
     __shared__ uint64_t or8[FE_BATCH / 8][4];
     __shared__ uint64_t gor[FE_BATCH / 64][4];
@@ -477,52 +478,64 @@ __global__ void __launch_bounds__(1024) frame_extent_kernel(const int32_t *__res
         }
     }
     const int lx = chunk * 256 + 4 * ci + ck;
-    if (k < 4 && lx < qw) {
+    if (k < 4 && lx < cstride) { // (the padding columns qw .. cstride-1 hold no pixel: INT_MAX / -1)
         cols[lx] = mytop;
-        cols[qw + lx] = mybot;
+        cols[cstride + lx] = mybot;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3 (gradient path).  Tile = 256 pixels x 8 rows of Q; only pixels inside the ROI are blended.
-// mosaic_q = the arena pixel under canvas (qx0, qy0).  A pixel outside every feather band has mask 1 (warped
-// channel > 0) or 0, for which  warped*mask + ref*(1-mask)  is exactly the warped or the reference byte: waves
-// without a feathered pixel skip the float64 arithmetic altogether.
+// K3 (gradient path).  A wave owns a tile of 64 pixels x 4 rows of Q (lane = 4 pixels of one row), a workgroup four
+// such tiles side by side, G3_IT row groups deep.  Narrow tiles keep the waves that meet a feather band (10 px wide,
+// along the frame's outline) few; everything else is byte-parallel on the packed quads: outside every feather band
+// the mask is 1 (warped channel > 0) or 0, for which  warped*mask + ref*(1-mask)  is exactly the warped or the
+// reference byte, i.e. a select on "warped byte != 0" -- 8 vector ops per dword instead of ~5 per byte, and this
+// kernel is bound by its instruction count, not by its bytes.  mosaic_q = the arena pixel under canvas (qx0, qy0);
+// cols = {top[cstride], bottom[cstride]}.
 // ------------------------------------------------------------------------------------------------
+#define G3_IT 1
 template <int C>
 __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__restrict__ wbuf, int64_t wpitch,
                                                              uint8_t *mosaic_q, int64_t mpitch, int qx0, int qy0,
                                                              int qw, int qh, const int32_t *__restrict__ rows,
-                                                             const int32_t *__restrict__ cols, int feather,
+                                                             const int32_t *__restrict__ cols, int cstride, int feather,
                                                              int clip_y0, int clip_y1, const int32_t *__restrict__ res,
                                                              int32_t *__restrict__ part) {
+    constexpr int NW = QuadRaw<C>::N;
     // per-workgroup partial {minx, miny, maxx, maxy, zeroed, dirty} (plain stores, folded on the host)
     int32_t *mypart = part + 6 * (blockIdx.y * gridDim.x + blockIdx.x);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lx = blockIdx.x * 256 + 4 * lane, X = qx0 + lx;
-    const int lyb = blockIdx.y * 8 + wave;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, lr = lane >> 4;
+    // consecutive workgroup ids go to different XCDs (id % 8) and gridDim.x is the number of 256-pixel column chunks,
+    // often 8: without the rotation one XCD would own a whole column of tiles -- e.g. every tile on the frame's left
+    // feather band, the expensive ones
+    const int bx = (int)((blockIdx.x + blockIdx.y) % gridDim.x);
+    const int lxw = bx * 256 + wave * 64, lx = lxw + 4 * l16, X = qx0 + lx, Xw = qx0 + lxw;
+    const int lyb = blockIdx.y * (4 * G3_IT); // first row of the workgroup
     // every load of the lane is issued before anything depends on the result block (one memory round trip)
-    uint32_t pw[2][4], pr[2][4];
-    int T[4], B[4], L[2], R[2];
+    uint32_t dw[G3_IT][NW], dr[G3_IT][NW];
+    int L[G3_IT], R[G3_IT];
+    int4 T = make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX), B = make_int4(-1, -1, -1, -1);
     const int4 *rt = (const int4 *)rows;
-    if (lx < qw) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int ly = min(lyb + 4 * i, qh - 1);
-            quad_load<C>(wbuf + (int64_t)ly * wpitch, lx, qw, pw[i]);
-            // (rows of another strip are not addressable in this GPU's arena)
-            quad_load<C>(mosaic_q + (int64_t)ly * mpitch, lx, (qy0 + ly >= clip_y0 && qy0 + ly < clip_y1) ? qw : 0, pr[i]);
-            const int4 e = rt[ly];
-            L[i] = e.z;
-            R[i] = e.w;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int xc = min(lx + k, qw - 1);
-            T[k] = cols[xc];
-            B[k] = cols[qw + xc];
-        }
+    for (int it = 0; it < G3_IT; it++) {
+        const int ly = lyb + 4 * it + lr, lyc = min(ly, qh - 1), Y = qy0 + ly;
+        // (rows beyond Q and rows of another strip -- not addressable in this GPU's arena -- read as 0)
+        const bool rd = lx < qw && ly < qh;
+        raw_load<C>(wbuf + (int64_t)lyc * wpitch, lx, rd ? qw : 0, dw[it]);
+        raw_load<C>(mosaic_q + (int64_t)lyc * mpitch, lx, (rd && Y >= clip_y0 && Y < clip_y1) ? qw : 0, dr[it]);
+#ifdef ISX_DIAG_K3_NOFEATHER
+        L[it] = INT_MAX, R[it] = -1;
+#else
+        const int4 e = rt[lyc];
+        L[it] = e.z, R[it] = e.w;
+#endif
     }
+#ifndef ISX_DIAG_K3_NOFEATHER
+    if (lx < qw) { // (cstride is a multiple of 4 and >= qw: the 16-byte loads stay inside the two arrays)
+        T = *(const int4 *)(cols + lx);
+        B = *(const int4 *)(cols + cstride + lx);
+    }
+#endif
     const int found = res[R_WBBOX + 4], rows_ok = res[R_ROWS_OK];
     // ROI rows [ry0, ry1) clip the feather bands; rows outside [clip_y0, clip_y1) belong to another strip of the mosaic
     // (another GPU) and are never read or written here: [gy0, gy1) is what this call blends
@@ -535,91 +548,134 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
     if (threadIdx.x <= feather) ftab[threadIdx.x] = (double)(int)threadIdx.x / (double)feather;
     if (threadIdx.x == 0) mypart[0] = mypart[1] = INT_MAX, mypart[2] = mypart[3] = -1, mypart[4] = mypart[5] = 0;
     if (!found || !rows_ok) return;
-    // tile entirely outside the ROI (block-uniform)
-    if (qx0 + (int)blockIdx.x * 256 >= gx1 || qx0 + (int)blockIdx.x * 256 + 256 <= gx0 || qy0 + (int)blockIdx.y * 8 >= gy1 ||
-        qy0 + (int)blockIdx.y * 8 + 8 <= gy0)
+    // workgroup entirely outside the ROI (block-uniform)
+    if (qx0 + bx * 256 >= gx1 || qx0 + bx * 256 + 256 <= gx0 || qy0 + lyb >= gy1 ||
+        qy0 + lyb + 4 * G3_IT <= gy0)
         return;
     __syncthreads();
-    const bool active = lx < qw && X < gx1 && X + 4 > gx0;
-    bool feathered = false;
-    if (active) {
-        // does any pixel of this lane sit in a feather band (conservative: clipping only shrinks the bands)
+    const int T4[4] = {T.x, T.y, T.z, T.w}, B4[4] = {B.x, B.y, B.z, B.w};
+    const bool cols_all = Xw >= gx0 && Xw + 64 <= gx1 && lxw + 64 <= qw;     // wave-uniform
+    const bool wave_out = Xw >= gx1 || Xw + 64 <= gx0 || lxw >= qw;         // wave-uniform
+    int sminx = INT_MAX, sminy = INT_MAX, smaxx = -1, smaxy = -1;           // wave-uniform (fast path)
+    int vminx = INT_MAX, vminy = INT_MAX, vmaxx = -1, vmaxy = -1;           // per lane (general path)
+    bool zeroed = false, dirty = false, any_general = false;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int Y = qy0 + lyb + 4 * i;
-            if (R[i] >= 0 && ((X + 3 >= L[i] && X < L[i] + feather) || (X + 3 >= R[i] - feather && X <= R[i]))) feathered = true;
+    for (int it = 0; it < G3_IT; it++) {
+        const int lyw = lyb + 4 * it, Yw = qy0 + lyw; // first row of the wave's tile (wave-uniform)
+        if (wave_out || Yw >= gy1 || Yw + 4 <= gy0 || lyw >= qh) continue;
+        const int ly = lyw + lr, Y = qy0 + ly;
+        // does any pixel of this lane sit in a feather band (conservative: clipping only shrinks the bands).  An empty
+        // row / column has L = T = INT_MAX, R = B = -1: the unsigned differences are then huge
+        bool feathered = (unsigned)(X + 3 - L[it]) < (unsigned)(feather + 3) || (unsigned)(R[it] - X) <= (unsigned)(feather + 3);
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (B[k] >= 0 && ((Y >= T[k] && Y < T[k] + feather) || (Y >= B[k] - feather && Y <= B[k]))) feathered = true;
-        }
-    }
+        for (int k = 0; k < 4; k++)
+            feathered = feathered || (unsigned)(Y - T4[k]) < (unsigned)feather || (unsigned)(B4[k] - Y) <= (unsigned)feather;
 #ifdef ISX_DIAG_K3_NOSLOW
-    const bool slow = false;
+        const bool slow = false;
 #else
-    const bool slow = __any(feathered);
+        const bool slow = __any(feathered);
 #endif
-    int minx = INT_MAX, miny = INT_MAX, maxx = -1, maxy = -1; // wave-uniform from here on
-    bool zeroed = false, dirty = false;
+        const bool rows_all = Yw >= gy0 && Yw + 4 <= gy1 && lyw + 4 <= qh; // wave-uniform
+        if (cols_all && rows_all && !slow) {
+            // ---- byte-parallel path: every pixel of the tile is inside the ROI and outside every feather band ----
+            uint32_t any_w = 0;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int ly = lyb + 4 * i, Y = qy0 + ly;
-        const bool row_in = ly < qh && Y >= gy0 && Y < gy1; // wave-uniform
-        if (!row_in) continue;
-        uint32_t po[4];
-        bool nz[4];
+            for (int j = 0; j < NW; j++) any_w |= dw[it][j];
+            // nothing warped onto this tile (the ROI's 50 px margin): the mosaic stays as it is.  Its gray != 0 pixels
+            // lie inside the old mosaic rectangle already, so they need not be reported
+            if (!__any(any_w != 0u)) continue;
+            uint32_t o[NW];
+#pragma unroll
+            for (int j = 0; j < NW; j++) o[j] = dw[it][j] | (dr[it][j] & ~nz_bytes(dw[it][j]));
+            raw_store<C>(mosaic_q + (int64_t)ly * mpitch, lx, qw, o);
+#ifdef ISX_DIAG_K3_NOBOOK
+            if (true) {
+#else
+            if (__all(raw_all_gray_nz<C>(o))) { // the whole tile is written with gray != 0
+#endif
+                sminx = min(sminx, Xw), smaxx = max(smaxx, Xw + 64), sminy = min(sminy, Yw), smaxy = max(smaxy, Yw + 4);
+            } else {
+                uint32_t po[4], pr[4];
+                raw_unpack<C>(o, po);
+                raw_unpack<C>(dr[it], pr);
+                any_general = true;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (gray_px<C>(po[k]) != 0) {
+                        vminx = min(vminx, X + k), vmaxx = max(vmaxx, X + k + 1), vminy = min(vminy, Y), vmaxy = max(vmaxy, Y + 1);
+                    } else {
+                        dirty = dirty || po[k] != 0u;
+                        zeroed = zeroed || gray_px<C>(pr[k]) != 0;
+                    }
+                }
+            }
+            continue;
+        }
+        // ---- general path: per pixel, ROI borders and feather bands ----
+#ifdef ISX_DIAG_K3_NOGENERAL
+        continue;
+#endif
+        any_general = true;
+        const bool row_in = ly < qh && Y >= gy0 && Y < gy1;
+        uint32_t pw[4], pr[4], po[4];
+        raw_unpack<C>(dw[it], pw);
+        raw_unpack<C>(dr[it], pr);
+        bool any_in = false;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int xx = X + k;
-            const bool in = active && xx >= gx0 && xx < gx1 && lx + k < qw;
+            const bool in = row_in && xx >= gx0 && xx < gx1 && lx + k < qw;
             uint32_t o = 0;
             if (!slow) {
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    const uint32_t wv = (pw[i][k] >> (8 * c)) & 255u, rv = (pr[i][k] >> (8 * c)) & 255u;
+                    const uint32_t wv = (pw[k] >> (8 * c)) & 255u, rv = (pr[k] >> (8 * c)) & 255u;
                     o |= (wv ? wv : rv) << (8 * c);
                 }
             } else {
                 // factor chain of proc.py:211-246 in ROI-relative form: [L, min(L+f, W)) and [max(0, R-f), R].  Branch
                 // free: a factor that does not apply is read as ftab[feather] = 1.0 (an exact no-op), so the four
                 // LDS reads of a pixel are in flight together
-                const int xe = L[i] + feather < gx1 ? L[i] + feather : gx1, xb = R[i] - feather > gx0 ? R[i] - feather : gx0;
-                const int ye = T[k] + feather < ry1 ? T[k] + feather : ry1, yb = B[k] - feather > ry0 ? B[k] - feather : ry0;
-                const int i0 = (R[i] >= 0 && xx >= L[i] && xx < xe) ? xx - L[i] : feather;
-                const int i1 = (R[i] >= 0 && xx >= xb && xx <= R[i]) ? R[i] - xx : feather;
-                const int i2 = (B[k] >= 0 && Y >= T[k] && Y < ye) ? Y - T[k] : feather;
-                const int i3 = (B[k] >= 0 && Y >= yb && Y <= B[k]) ? B[k] - Y : feather;
+                const int Lr = L[it], Rr = R[it];
+                const int xe = Lr + feather < gx1 ? Lr + feather : gx1, xb = Rr - feather > gx0 ? Rr - feather : gx0;
+                const int ye = T4[k] + feather < ry1 ? T4[k] + feather : ry1, yb = B4[k] - feather > ry0 ? B4[k] - feather : ry0;
+                const int i0 = (Rr >= 0 && xx >= Lr && xx < xe) ? xx - Lr : feather;
+                const int i1 = (Rr >= 0 && xx >= xb && xx <= Rr) ? Rr - xx : feather;
+                const int i2 = (B4[k] >= 0 && Y >= T4[k] && Y < ye) ? Y - T4[k] : feather;
+                const int i3 = (B4[k] >= 0 && Y >= yb && Y <= B4[k]) ? B4[k] - Y : feather;
                 const double m = ((ftab[i0] * ftab[i1]) * ftab[i2]) * ftab[i3];
 #pragma unroll
                 for (int c = 0; c < C; c++) {
-                    const int wv = (pw[i][k] >> (8 * c)) & 255, rv = (pr[i][k] >> (8 * c)) & 255;
+                    const int wv = (pw[k] >> (8 * c)) & 255, rv = (pr[k] >> (8 * c)) & 255;
                     const double mk = wv > 0 ? m : 0.0;
                     const double r = (double)wv * mk + (double)rv * (1 - mk);
                     o |= (uint32_t)(uint8_t)(int)r << (8 * c);
                 }
             }
-            po[k] = in ? o : pr[i][k];
-            const bool g = in && gray_px<C>(o) != 0;
-            nz[k] = g;
-            dirty = dirty || (in && !g && o != 0u);
-            zeroed = zeroed || (in && !g && gray_px<C>(pr[i][k]) != 0);
-        }
-        if (active) quad_store<C>(mosaic_q + (int64_t)ly * mpitch, lx, qw, po);
-        // bbox of the written gray != 0 pixels from ballots (bit l of word k = pixel 4*l + k of the chunk)
-        const int cx = qx0 + (int)blockIdx.x * 256;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t bm = __ballot(nz[k]);
-            if (bm) {
-                minx = min(minx, cx + 4 * (int)__builtin_ctzll(bm) + k);
-                maxx = max(maxx, cx + 4 * (63 - (int)__builtin_clzll(bm)) + k + 1);
-                miny = min(miny, Y);
-                maxy = max(maxy, Y + 1);
+            po[k] = in ? o : pr[k];
+            any_in = any_in || in;
+            if (in) {
+                if (gray_px<C>(o) != 0) {
+                    vminx = min(vminx, xx), vmaxx = max(vmaxx, xx + 1), vminy = min(vminy, Y), vmaxy = max(vmaxy, Y + 1);
+                } else {
+                    dirty = dirty || o != 0u;
+                    zeroed = zeroed || gray_px<C>(pr[k]) != 0;
+                }
             }
         }
+        if (any_in) { // (pixels of the quad outside the ROI are written back unchanged)
+            uint32_t o[NW];
+            raw_pack<C>(po, o);
+            raw_store<C>(mosaic_q + (int64_t)ly * mpitch, lx, qw, o);
+        }
+    }
+    if (__any(any_general)) {
+        sminx = min(sminx, wave_min(vminx)), sminy = min(sminy, wave_min(vminy));
+        smaxx = max(smaxx, wave_max(vmaxx)), smaxy = max(smaxy, wave_max(vmaxy));
     }
     const int zf = __any(zeroed), df = __any(dirty);
     if (lane == 0)
-        red[wave][0] = minx, red[wave][1] = miny, red[wave][2] = maxx, red[wave][3] = maxy, red[wave][4] = zf, red[wave][5] = df;
+        red[wave][0] = sminx, red[wave][1] = sminy, red[wave][2] = smaxx, red[wave][3] = smaxy, red[wave][4] = zf, red[wave][5] = df;
     __syncthreads();
     if (threadIdx.x == 0) {
         int a0 = red[0][0], a1 = red[0][1], a2 = red[0][2], a3 = red[0][3], a4 = red[0][4], a5 = red[0][5];
@@ -759,11 +815,12 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
     WarpParams P;
     if (blender == ISX_BLEND_GRADIENT) {
         const int64_t wpitch = (int64_t)q_w * c;
-        dim3 gb(nchunk, (q_h + 7) / 8);
+        dim3 gb(nchunk, (q_h + 4 * G3_IT - 1) / (4 * G3_IT));
+        const int cstride = (q_w + 3) & ~3;
         const int n_part = (int)(gb.x * gb.y);
         if ((rc = ctx_ensure(&ctx->wbuf, &ctx->wbuf_cap, (size_t)wpitch * q_h + 16)) != ISX_OK) return rc;
         if ((rc = ctx_ensure(&ctx->rows, &ctx->rows_cap, (size_t)4 * q_h)) != ISX_OK) return rc;
-        if ((rc = ctx_ensure(&ctx->cols, &ctx->cols_cap, (size_t)2 * q_w)) != ISX_OK) return rc;
+        if ((rc = ctx_ensure(&ctx->cols, &ctx->cols_cap, (size_t)2 * cstride)) != ISX_OK) return rc;
         if ((rc = ctx_ensure(&ctx->mask, &ctx->mask_cap, (size_t)q_h * nchunk * 4)) != ISX_OK) return rc;
         if ((rc = ctx_ensure_out(ctx, (size_t)R_INTS + (size_t)6 * n_part)) != ISX_OK) return rc;
         fill_warp_params(P, M_host, model, arith, canvas_w, canvas_h, sh, sw, spitch, src_x, src_y, q_x0, q_y0, q_w, q_h, wpitch);
@@ -783,13 +840,13 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
         }
 #undef ISX_FW_LAUNCH
         hipLaunchKernelGGL(frame_extent_kernel, dim3(nchunk), dim3(1024), 0, st, ctx->rows, q_x0, q_y0, q_w, q_h, canvas_w,
-                           canvas_h, 50, ctx->mask, nchunk, ctx->cols, ctx->out_dev);
+                           canvas_h, 50, ctx->mask, nchunk, ctx->cols, cstride, ctx->out_dev);
         if (c == 3)
             hipLaunchKernelGGL((frame_gradient_kernel<3>), gb, dim3(256), 0, st, ctx->wbuf, wpitch, mosaic_q_dev, mpitch, q_x0,
-                               q_y0, q_w, q_h, ctx->rows, ctx->cols, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
+                               q_y0, q_w, q_h, ctx->rows, ctx->cols, cstride, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
         else
             hipLaunchKernelGGL((frame_gradient_kernel<1>), gb, dim3(256), 0, st, ctx->wbuf, wpitch, mosaic_q_dev, mpitch, q_x0,
-                               q_y0, q_w, q_h, ctx->rows, ctx->cols, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
+                               q_y0, q_w, q_h, ctx->rows, ctx->cols, cstride, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
         ctx->fold_n = n_part;
         ctx->pending = 1;
     } else {

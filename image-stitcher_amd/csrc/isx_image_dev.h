@@ -87,6 +87,81 @@ __device__ __forceinline__ void quad_store(uint8_t *__restrict__ row, int x, int
     }
 }
 
+// The same quad kept PACKED, as the 3 (C=3) or 1 (C=1) dwords that hold its 4*C bytes: byte-parallel kernels work on
+// these directly and only unpack to pixels where per-pixel arithmetic is needed.
+template <int C>
+struct QuadRaw {
+    static constexpr int N = C == 3 ? 3 : 1;
+};
+template <int C>
+__device__ __forceinline__ void raw_load(const uint8_t *__restrict__ row, int x, int w, uint32_t (&d)[QuadRaw<C>::N]) {
+    const uint8_t *p = row + (int64_t)x * C;
+    if (x + 4 <= w) {
+        if (C == 3) {
+            const u96u v = *(const u96u *)p;
+            d[0] = v.a, d[1] = v.b, d[2] = v.c;
+        } else {
+            d[0] = *(const u32u *)p;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < QuadRaw<C>::N; j++) d[j] = 0u;
+#pragma unroll
+        for (int b = 0; b < 4 * C; b++)
+            if (x + b / C < w) d[b >> 2] |= (uint32_t)p[b] << (8 * (b & 3));
+    }
+}
+template <int C>
+__device__ __forceinline__ void raw_store(uint8_t *__restrict__ row, int x, int w, const uint32_t (&d)[QuadRaw<C>::N]) {
+    uint8_t *p = row + (int64_t)x * C;
+    if (x + 4 <= w) {
+        if (C == 3) {
+            u96u v;
+            v.a = d[0], v.b = d[1], v.c = d[2];
+            *(u96u *)p = v;
+        } else {
+            *(u32u *)p = d[0];
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4 * C; b++)
+            if (x + b / C < w) p[b] = (uint8_t)(d[b >> 2] >> (8 * (b & 3)));
+    }
+}
+template <int C>
+__device__ __forceinline__ void raw_unpack(const uint32_t (&d)[QuadRaw<C>::N], uint32_t (&px)[4]) {
+    if (C == 3) {
+        px[0] = d[0] & 0xFFFFFFu;
+        px[1] = (d[0] >> 24) | ((d[1] & 0xFFFFu) << 8);
+        px[2] = (d[1] >> 16) | ((d[2] & 0xFFu) << 16);
+        px[3] = d[2] >> 8;
+    } else {
+        px[0] = d[0] & 255u, px[1] = (d[0] >> 8) & 255u, px[2] = (d[0] >> 16) & 255u, px[3] = d[0] >> 24;
+    }
+}
+template <int C>
+__device__ __forceinline__ void raw_pack(const uint32_t (&px)[4], uint32_t (&d)[QuadRaw<C>::N]) {
+    if (C == 3) {
+        d[0] = px[0] | (px[1] << 24);
+        d[1] = (px[1] >> 8) | (px[2] << 16);
+        d[2] = (px[2] >> 16) | (px[3] << 8);
+    } else {
+        d[0] = px[0] | (px[1] << 8) | (px[2] << 16) | (px[3] << 24);
+    }
+}
+// 0xFF in every byte of w that is != 0
+__device__ __forceinline__ uint32_t nz_bytes(uint32_t w) {
+    const uint32_t a = (((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;
+    return a | (a - (a >> 7));
+}
+// sufficient (not necessary) test that all four pixels of a packed quad have gray != 0: the G byte of a BGR pixel
+// alone carries 19235 >= 16384 (gray3), for C = 1 the byte is the gray value
+template <int C>
+__device__ __forceinline__ bool raw_all_gray_nz(const uint32_t (&d)[QuadRaw<C>::N]) {
+    if (C == 3) return (d[0] & 0xFF00u) != 0u && (d[1] & 0xFFu) != 0u && d[1] > 0xFFFFFFu && (d[2] & 0xFF0000u) != 0u;
+    return nz_bytes(d[0]) == 0xFFFFFFFFu;
+}
+
 template <int C>
 __device__ __forceinline__ void bbox_quad(const uint32_t (&px)[4], int x, int y, int &minx, int &miny, int &maxx,
                                           int &maxy) {
