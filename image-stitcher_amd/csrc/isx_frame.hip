@@ -155,7 +155,11 @@ __device__ __forceinline__ void warp_quad_f32(const uint8_t *__restrict__ src, c
             const uint8_t *r0 = src + off;
             uint32_t o = 0;
             if (C == 3) {
+#ifdef ISX_DIAG_K1_NOLOAD
+                const uint64_t q0 = off * 0x0101010101ull, q1 = q0 + sp;
+#else
                 const uint64_t q0 = *(const u64u *)r0, q1 = *(const u64u *)(r0 + sp);
+#endif
                 const uint32_t q0l = (uint32_t)q0, q0h = (uint32_t)(q0 >> 32), q1l = (uint32_t)q1, q1h = (uint32_t)(q1 >> 32);
                 // taps: bytes 0..2 = left pixel, bytes 3..5 = right pixel
                 const float f00[3] = {(float)(q0l & 255u), (float)((q0l >> 8) & 255u), (float)((q0l >> 16) & 255u)};
@@ -195,21 +199,51 @@ __device__ __forceinline__ void warp_quad_f32(const uint8_t *__restrict__ src, c
     // clamped coordinates and masked afterwards, so the 16 loads of a lane are in flight together (the per-tap
     // branches of warp_pixel serialise up to 12 memory round trips per pixel, and one such wave sets the kernel time)
     uint32_t t00[4], t01[4], t10[4], t11[4];
+    if (C == 3 && P.sw * 3 >= 8) {
+        // BGR: both taps of a row come out of ONE 8-byte load whose start is clamped into the row; a byte permute picks
+        // the three bytes of each tap (or zeros for a tap outside the frame): 8 loads per lane instead of 16 and no
+        // per-tap masking afterwards
+        const uint32_t sp = (uint32_t)P.spitch;
+        uint64_t q0[4], q1[4];
+        int offx[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int cx0 = min(max(ix[i], 0), P.sw - 1), cx1 = min(max(ix[i] + 1, 0), P.sw - 1);
-        const int cy0 = min(max(iy[i], 0), P.sh - 1), cy1 = min(max(iy[i] + 1, 0), P.sh - 1);
-        t00[i] = tap_clamped<C>(src, P, cx0, cy0);
-        t01[i] = tap_clamped<C>(src, P, cx1, cy0);
-        t10[i] = tap_clamped<C>(src, P, cx0, cy1);
-        t11[i] = tap_clamped<C>(src, P, cx1, cy1);
+        for (int i = 0; i < 4; i++) {
+            const int cy0 = min(max(iy[i], 0), P.sh - 1), cy1 = min(max(iy[i] + 1, 0), P.sh - 1);
+            offx[i] = min(max(ix[i] * 3, 0), P.sw * 3 - 8);
+            q0[i] = *(const u64u *)(src + ((uint32_t)cy0 * sp + (uint32_t)offx[i]));
+            q1[i] = *(const u64u *)(src + ((uint32_t)cy1 * sp + (uint32_t)offx[i]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool x0ok = (unsigned)ix[i] < (unsigned)P.sw, x1ok = (unsigned)(ix[i] + 1) < (unsigned)P.sw;
+            const bool y0ok = guard[i] && (unsigned)iy[i] < (unsigned)P.sh, y1ok = guard[i] && (unsigned)(iy[i] + 1) < (unsigned)P.sh;
+            // selector bytes {k, k+1, k+2, 0x0C = constant 0} with k = the tap's byte offset inside the 8 loaded bytes
+            // (0..5 whenever the tap is inside the frame)
+            const uint32_t kl = (uint32_t)(ix[i] * 3 - offx[i]), kr = kl + 3u;
+            const uint32_t sl = x0ok ? 0x0C020100u + kl * 0x00010101u : 0x0C0C0C0Cu;
+            const uint32_t sr = x1ok ? 0x0C020100u + kr * 0x00010101u : 0x0C0C0C0Cu;
+            const uint32_t l0 = (uint32_t)q0[i], h0 = (uint32_t)(q0[i] >> 32), l1 = (uint32_t)q1[i], h1 = (uint32_t)(q1[i] >> 32);
+            t00[i] = y0ok ? __builtin_amdgcn_perm(h0, l0, sl) : 0u;
+            t01[i] = y0ok ? __builtin_amdgcn_perm(h0, l0, sr) : 0u;
+            t10[i] = y1ok ? __builtin_amdgcn_perm(h1, l1, sl) : 0u;
+            t11[i] = y1ok ? __builtin_amdgcn_perm(h1, l1, sr) : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int cx0 = min(max(ix[i], 0), P.sw - 1), cx1 = min(max(ix[i] + 1, 0), P.sw - 1);
+            const int cy0 = min(max(iy[i], 0), P.sh - 1), cy1 = min(max(iy[i] + 1, 0), P.sh - 1);
+            const bool x0ok = (unsigned)ix[i] < (unsigned)P.sw, x1ok = (unsigned)(ix[i] + 1) < (unsigned)P.sw;
+            const bool y0ok = (unsigned)iy[i] < (unsigned)P.sh, y1ok = (unsigned)(iy[i] + 1) < (unsigned)P.sh;
+            const uint32_t a00 = tap_clamped<C>(src, P, cx0, cy0), a01 = tap_clamped<C>(src, P, cx1, cy0);
+            const uint32_t a10 = tap_clamped<C>(src, P, cx0, cy1), a11 = tap_clamped<C>(src, P, cx1, cy1);
+            t00[i] = (guard[i] && x0ok && y0ok) ? a00 : 0u, t01[i] = (guard[i] && x1ok && y0ok) ? a01 : 0u;
+            t10[i] = (guard[i] && x0ok && y1ok) ? a10 : 0u, t11[i] = (guard[i] && x1ok && y1ok) ? a11 : 0u;
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const bool x0ok = (unsigned)ix[i] < (unsigned)P.sw, x1ok = (unsigned)(ix[i] + 1) < (unsigned)P.sw;
-        const bool y0ok = (unsigned)iy[i] < (unsigned)P.sh, y1ok = (unsigned)(iy[i] + 1) < (unsigned)P.sh;
-        const uint32_t p00 = (guard[i] && x0ok && y0ok) ? t00[i] : 0u, p01 = (guard[i] && x1ok && y0ok) ? t01[i] : 0u;
-        const uint32_t p10 = (guard[i] && x0ok && y1ok) ? t10[i] : 0u, p11 = (guard[i] && x1ok && y1ok) ? t11[i] : 0u;
+        const uint32_t p00 = t00[i], p01 = t01[i], p10 = t10[i], p11 = t11[i];
         const float a = sx[i] - flx[i], b = sy[i] - fly[i];
         uint32_t o = 0;
 #pragma unroll
@@ -238,18 +272,34 @@ __device__ __forceinline__ void warp_quad(const uint8_t *__restrict__ src, const
 // K1 (gradient path).  grid = qh workgroups of nw = min(nchunk, 16) waves; wave w takes the 256-pixel chunks
 // w, w+nw, ... of its row (one chunk per wave up to 4096-pixel rows).
 // ------------------------------------------------------------------------------------------------
+#ifndef ISX_K1_WAVES
+#define ISX_K1_WAVES 6
+#endif
 template <int C, bool PERSP, bool CLASSIC>
-__global__ void __launch_bounds__(1024) frame_warp_kernel(const uint8_t *__restrict__ src, const WarpParams P,
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ISX_K1_WAVES))) frame_warp_kernel(const uint8_t *__restrict__ src, const WarpParams P,
                                                           uint8_t *__restrict__ wbuf, int nchunk,
                                                           int32_t *__restrict__ rows, uint64_t *__restrict__ mask) {
     const int ly = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int gl = INT_MAX, gr = -1, l0 = INT_MAX, r0 = -1;
-    for (int chunk = wave; chunk < nchunk; chunk += nw) {
+    __shared__ uint64_t mw[(ISX_FRAME_MAX_Q / 256) * 4];
+    for (int cw = wave; cw < nchunk; cw += nw) {
+        // the chunk a wave takes rotates with the row: the frame's left and right borders (the expensive general path of
+        // warp_quad) sit in the same two chunks of every row, and a fixed wave -> chunk map would give all of them to the
+        // same two SIMDs of every CU (wave w runs on SIMD w % 4)
+        const int chunk = (cw + ly) % nchunk;
         const int lx = chunk * 256 + 4 * lane;
         const int nv = min(4, max(0, P.dw - lx));
         uint32_t px[4];
         warp_quad<C, PERSP, CLASSIC>(src, P, P.dx0 + lx, P.dy0 + ly, nv, px);
+#ifndef ISX_DIAG_K1_NOSTORE
         if (nv > 0) quad_store<C>(wbuf + (int64_t)ly * P.dpitch, lx, P.dw, px);
+#else
+        if (px[0] + px[1] + px[2] + px[3] == 0x7FFFFFFFu) wbuf[0] = 1;
+#endif
+#ifdef ISX_DIAG_K1_NOPOST
+        if (px[0] == 0x7FFFFFFFu) gl = 0;
+        continue;
+#endif
         // extents from ballots: bit l of word i is pixel 4*l + i of the chunk; the scalar unit finds the first / last
         // set bit, no per-lane min/max and no cross-lane reduction
         uint64_t bc[4], bg[4];
@@ -270,22 +320,30 @@ __global__ void __launch_bounds__(1024) frame_warp_kernel(const uint8_t *__restr
                 r0 = max(r0, cx + 4 * (63 - (int)__builtin_clzll(bc[i])) + i);
             }
         }
-        if (lane == 0) {
-            uint64_t *m = mask + ((int64_t)ly * nchunk + chunk) * 4;
-            m[0] = bc[0], m[1] = bc[1], m[2] = bc[2], m[3] = bc[3];
-        }
+        if (lane < 4) mw[chunk * 4 + lane] = lane == 0 ? bc[0] : lane == 1 ? bc[1] : lane == 2 ? bc[2] : bc[3];
     }
-    __shared__ int red[FRAME_MAX_WAVES][4];
+    __shared__ __align__(16) int red[FRAME_MAX_WAVES][4];
     if (lane == 0) red[wave][0] = gl, red[wave][1] = gr, red[wave][2] = l0, red[wave][3] = r0; // (wave-uniform values)
     __syncthreads();
-    if (threadIdx.x == 0) {
+    // The bit mask goes to memory as the HORIZONTALLY FEATHERED mask's support: the feather factor is 0 at both edges of
+    // the row (alpha = 0 / f, proc.py:222, :226), so the row's first and last channel-0 pixel are cleared here, where
+    // the row's extent is known -- K2 then only has to OR rows.  Layout [chunk][row][4]: K2 reads a chunk's rows
+    // contiguously.
+    if ((int)threadIdx.x < nchunk * 4) { // (nchunk >= 1: thread 0 is always here)
+        int4 f = *(const int4 *)red[0];
         for (int w = 1; w < nw; w++) {
-            gl = min(gl, red[w][0]);
-            gr = max(gr, red[w][1]);
-            l0 = min(l0, red[w][2]);
-            r0 = max(r0, red[w][3]);
+            const int4 e = *(const int4 *)red[w];
+            f.x = min(f.x, e.x), f.y = max(f.y, e.y), f.z = min(f.z, e.z), f.w = max(f.w, e.w);
         }
-        ((int4 *)rows)[ly] = make_int4(gl, gr, l0, r0);
+        if (threadIdx.x == 0) ((int4 *)rows)[ly] = f;
+        for (int w = threadIdx.x; w < nchunk * 4; w += blockDim.x) {
+            const int chunk = w >> 2, kk = w & 3, cx = P.dx0 + chunk * 256;
+            const int eL = f.z - cx, eR = f.w - cx; // (an empty row has l0 = INT_MAX, r0 = -1: both out of range)
+            uint64_t word = mw[w];
+            if ((unsigned)eL < 256u && (eL & 3) == kk) word &= ~(1ull << (eL >> 2));
+            if ((unsigned)eR < 256u && (eR & 3) == kk) word &= ~(1ull << (eR >> 2));
+            mask[((int64_t)chunk * gridDim.x + ly) * 4 + kk] = word;
+        }
     }
 }
 
@@ -328,28 +386,28 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
 // a kernel costs its dependent memory round trips, not its bytes.
 // ------------------------------------------------------------------------------------------------
 #define FE_ROWS_PER_THREAD ((FE_BATCH + 1023) / 1024)
-#define FE_WORDS_PER_THREAD ((FE_BATCH * 4 + 1023) / 1024)
+#define FE_PAIRS_PER_THREAD ((FE_BATCH * 2 + 1023) / 1024)
 __global__ void __launch_bounds__(1024) frame_extent_kernel(const int32_t *__restrict__ rows, int qx0, int qy0, int qw,
                                                             int qh, int canvas_w, int canvas_h, int margin,
                                                             const uint64_t *__restrict__ mask, int nchunk,
                                                             int32_t *__restrict__ cols, int cstride,
                                                             int32_t *__restrict__ res) {
-    __shared__ uint64_t wm[FE_BATCH][4];
+    __shared__ __align__(16) uint64_t wm[FE_BATCH][4];
     __shared__ uint64_t or8[FE_BATCH / 8][4];
     __shared__ uint64_t gor[FE_BATCH / 64][4];
     const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
-    const int chunk = blockIdx.x, cx0 = qx0 + chunk * 256; // canvas x of the chunk's first column
+    const int chunk = blockIdx.x;
     const int4 *rt = (const int4 *)rows;
     // ---- fold the row table: bbox of gray != 0 pixels; any channel-0 extent outside [lo, hi) is checked later ----
     int x0 = INT_MAX, y0 = INT_MAX, x1 = -1, y1 = -1, l0min = INT_MAX, r0max = -1;
-    uint64_t wv[FE_WORDS_PER_THREAD];
-    int4 wr[FE_WORDS_PER_THREAD];
+    // thread t of pass u moves the two words [r][kk], [r][kk + 1] with r = (t + 1024 u) / 2, kk = 2 (t & 1)
+    uint4 wv[FE_PAIRS_PER_THREAD];
+    const uint4 *mp = (const uint4 *)(mask + (int64_t)chunk * qh * 4);
     const int n0 = min(FE_BATCH, qh); // first batch: rows [0, n0) of Q
 #pragma unroll
-    for (int u = 0; u < FE_WORDS_PER_THREAD; u++) {
-        const int t = threadIdx.x + 1024 * u, r = min(t >> 2, n0 - 1);
-        wv[u] = mask[((int64_t)r * nchunk + chunk) * 4 + (t & 3)];
-        wr[u] = rt[r];
+    for (int u = 0; u < FE_PAIRS_PER_THREAD; u++) {
+        const int t = threadIdx.x + 1024 * u, r = min(t >> 1, n0 - 1);
+        wv[u] = mp[r * 2 + (t & 1)];
     }
     for (int ly = threadIdx.x; ly < qh; ly += 1024) {
         const int4 e = rt[ly];
@@ -399,6 +457,9 @@ __global__ void __launch_bounds__(1024) frame_extent_kernel(const int32_t *__res
         res[R_ROWS_OK] = !bad;
     }
     if (bad) return;
+#ifdef ISX_DIAG_K2_NOCOLS
+    return;
+#endif
     // ---- column extents.  Per batch of rows: stage the (edge-cleared, ROI-clipped) bit words in LDS, OR them per
     // 8 rows and per 64 rows, then ONE THREAD PER COLUMN walks group words -> 8-row words -> rows: three short
     // levels whose LDS reads are issued together (registers), no cross-lane traffic, no atomics, one writer per column.
@@ -410,23 +471,17 @@ __global__ void __launch_bounds__(1024) frame_extent_kernel(const int32_t *__res
         __syncthreads();
         if (bi > 0) { // (the first batch was fetched at the top of the kernel)
 #pragma unroll
-            for (int u = 0; u < FE_WORDS_PER_THREAD; u++) {
-                const int t = threadIdx.x + 1024 * u, r = min(t >> 2, n - 1);
-                wv[u] = mask[((int64_t)(base + r) * nchunk + chunk) * 4 + (t & 3)];
-                wr[u] = rt[base + r];
+            for (int u = 0; u < FE_PAIRS_PER_THREAD; u++) {
+                const int t = threadIdx.x + 1024 * u, r = min(t >> 1, n - 1);
+                wv[u] = mp[(base + r) * 2 + (t & 1)];
             }
         }
 #pragma unroll
-        for (int u = 0; u < FE_WORDS_PER_THREAD; u++) { // all FE_BATCH rows are written (zeros beyond n)
-            const int t = threadIdx.x + 1024 * u, r = t >> 2, kk = t & 3;
-            uint64_t w = r < n ? wv[u] : 0ull;
-            // the horizontally feathered mask is 0 at both edges of its row (alpha = 0/f): clear those bits;
-            // rows outside the ROI do not take part
-            const int eL = wr[u].z - cx0, eR = wr[u].w - cx0;
-            if (eL >= 0 && eL < 256 && (eL & 3) == kk) w &= ~(1ull << (eL >> 2));
-            if (eR >= 0 && eR < 256 && (eR & 3) == kk) w &= ~(1ull << (eR >> 2));
-            if (base + r < ly_lo || base + r >= ly_hi) w = 0ull;
-            if (r < FE_BATCH) wm[r][kk] = w;
+        for (int u = 0; u < FE_PAIRS_PER_THREAD; u++) { // all FE_BATCH rows are written (zeros beyond n)
+            const int t = threadIdx.x + 1024 * u, r = t >> 1;
+            // (K1 cleared the two edge bits of every row already); rows outside the ROI do not take part
+            const bool use = r < n && base + r >= ly_lo && base + r < ly_hi;
+            if (r < FE_BATCH) *(uint4 *)&wm[r][2 * (t & 1)] = use ? wv[u] : make_uint4(0u, 0u, 0u, 0u);
         }
         __syncthreads();
         if (threadIdx.x < (FE_BATCH / 8) * 4) { // OR of every 8 rows
@@ -445,42 +500,46 @@ __global__ void __launch_bounds__(1024) frame_extent_kernel(const int32_t *__res
             gor[g][kk] = o;
         }
         __syncthreads();
-        if (k < 4) {
-            int tg = -1, bg = -1;
-            {
-                bool h[FE_BATCH / 64];
+#ifdef ISX_DIAG_K2_NOWALK
+        if (false) {
+#else
+        if (k < 8) {
+#endif
+            // waves 0..3 look for the top row of their 64 columns, waves 4..7 for the bottom row: half the serial chain
+            // each.  Only the 32-bit half of a word that holds the lane's bit is read; the bits of a level are gathered
+            // into one mask (bfe + shift-or per word) and the row is its lowest / highest set bit
+            const bool top = k < 4;
+            const int half = ci >> 5, sh = ci & 31;
+            const uint32_t *g32 = (const uint32_t *)&gor[0][0] + ck * 2 + half;
+            const uint32_t *o32 = (const uint32_t *)&or8[0][0] + ck * 2 + half;
+            const uint32_t *w32 = (const uint32_t *)&wm[0][0] + ck * 2 + half;
+            uint32_t gm = 0;
 #pragma unroll
-                for (int g = 0; g < FE_BATCH / 64; g++) h[g] = (gor[g][ck] >> ci) & 1ull;
+            for (int g = 0; g < FE_BATCH / 64; g++) gm |= ((g32[g * 8] >> sh) & 1u) << g;
+            if (gm) {
+                const int g = top ? __builtin_ctz(gm) : 31 - __builtin_clz(gm);
+                uint32_t m8 = 0, m1 = 0;
 #pragma unroll
-                for (int g = FE_BATCH / 64 - 1; g >= 0; g--) tg = h[g] ? g : tg;
+                for (int r = 0; r < 8; r++) m8 |= ((o32[(g * 8 + r) * 8] >> sh) & 1u) << r;
+                const int s8 = top ? __builtin_ctz(m8) : 31 - __builtin_clz(m8);
+                const int row0 = (g * 8 + s8) * 8;
 #pragma unroll
-                for (int g = 0; g < FE_BATCH / 64; g++) bg = h[g] ? g : bg;
-            }
-            if (bg >= 0) {
-                bool ht[8], hb[8];
-                int ts = 0, bs = 0, tr = 0, br = 0;
-#pragma unroll
-                for (int r = 0; r < 8; r++) ht[r] = (or8[tg * 8 + r][ck] >> ci) & 1ull, hb[r] = (or8[bg * 8 + r][ck] >> ci) & 1ull;
-#pragma unroll
-                for (int r = 7; r >= 0; r--) ts = ht[r] ? r : ts;
-#pragma unroll
-                for (int r = 0; r < 8; r++) bs = hb[r] ? r : bs;
-                const int trow = (tg * 8 + ts) * 8, brow = (bg * 8 + bs) * 8;
-#pragma unroll
-                for (int r = 0; r < 8; r++) ht[r] = (wm[trow + r][ck] >> ci) & 1ull, hb[r] = (wm[brow + r][ck] >> ci) & 1ull;
-#pragma unroll
-                for (int r = 7; r >= 0; r--) tr = ht[r] ? r : tr;
-#pragma unroll
-                for (int r = 0; r < 8; r++) br = hb[r] ? r : br;
-                if (mytop == INT_MAX) mytop = qy0 + base + trow + tr;
-                mybot = qy0 + base + brow + br;
+                for (int r = 0; r < 8; r++) m1 |= ((w32[(row0 + r) * 8] >> sh) & 1u) << r;
+                const int row = qy0 + base + row0 + (top ? __builtin_ctz(m1) : 31 - __builtin_clz(m1));
+                if (top) {
+                    if (mytop == INT_MAX) mytop = row;
+                } else {
+                    mybot = row;
+                }
             }
         }
     }
     const int lx = chunk * 256 + 4 * ci + ck;
-    if (k < 4 && lx < cstride) { // (the padding columns qw .. cstride-1 hold no pixel: INT_MAX / -1)
-        cols[lx] = mytop;
-        cols[cstride + lx] = mybot;
+    if (k < 8 && lx < cstride) { // (the padding columns qw .. cstride-1 hold no pixel: INT_MAX / -1)
+        if (k < 4)
+            cols[lx] = mytop;
+        else
+            cols[cstride + lx] = mybot;
     }
 }
 
@@ -809,7 +868,10 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
     }
     ISX_REQUIRE(src_dev && mosaic_q_dev && mpitch >= (int64_t)q_w * c, "null device pointer / bad mosaic pitch");
     const int nchunk = (q_w + 255) / 256;
-    const int row_threads = 64 * (nchunk < FRAME_MAX_WAVES ? nchunk : FRAME_MAX_WAVES);
+    // waves per row workgroup: a wave per 256-pixel chunk for the warp kernel; the fused alpha kernel (120 VGPRs, 4 waves
+    // per SIMD) measured 1 us faster with four waves that take two chunks each at 1080p
+    const int max_waves = blender == ISX_BLEND_GRADIENT ? FRAME_MAX_WAVES : 4;
+    const int row_threads = 64 * (nchunk < max_waves ? nchunk : max_waves);
     const bool persp = model == ISX_MODEL_HOMOGRAPHY, classic = arith == ISX_WARP_CLASSIC;
     int rc;
     WarpParams P;
