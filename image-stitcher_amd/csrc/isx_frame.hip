@@ -169,15 +169,16 @@ __device__ __forceinline__ void warp_quad_f32(const uint8_t *__restrict__ src, c
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const float t0 = fmaf(a, f01[c] - f00[c], f00[c]), t1 = fmaf(a, f11[c] - f10[c], f10[c]);
-                    // a convex combination of bytes, rounded once per FMA: always inside [0, 255]; rintf first, so the
-                    // conversion inside the pack instruction has nothing left to round
-                    o = __builtin_amdgcn_cvt_pk_u8_f32(rintf(fmaf(b, t1 - t0, t0)), c, o);
+                    // v_cvt_pk_u8_f32 itself rounds to nearest, ties to even, and saturates (measured: 0.5 -> 0, 1.5 -> 2,
+                    // 2.5 -> 2, 254.5 -> 254, 300 -> 255, -1 -> 0; tools/valu_rate.hip) -- rintf + the cast of warp_pixel
+                    // in one 4-cycle instruction (the kernel runs in the default round-to-nearest-even mode)
+                    o = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(b, t1 - t0, t0), c, o);
                 }
             } else {
                 const uint32_t q0 = *(const u16u *)r0, q1 = *(const u16u *)(r0 + sp);
                 const float f00 = (float)(q0 & 255u), f01 = (float)(q0 >> 8), f10 = (float)(q1 & 255u), f11 = (float)(q1 >> 8);
                 const float t0 = fmaf(a, f01 - f00, f00), t1 = fmaf(a, f11 - f10, f10);
-                o = (uint32_t)(int)rintf(fmaf(b, t1 - t0, t0));
+                o = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(b, t1 - t0, t0), 0, 0u);
             }
             px[i] = o;
         }
@@ -251,7 +252,7 @@ __device__ __forceinline__ void warp_quad_f32(const uint8_t *__restrict__ src, c
             const float f00 = (float)((p00 >> (8 * c)) & 255u), f01 = (float)((p01 >> (8 * c)) & 255u);
             const float f10 = (float)((p10 >> (8 * c)) & 255u), f11 = (float)((p11 >> (8 * c)) & 255u);
             const float t0 = fmaf(a, f01 - f00, f00), t1 = fmaf(a, f11 - f10, f10);
-            o |= (uint32_t)(int)rintf(fmaf(b, t1 - t0, t0)) << (8 * c);
+            o = __builtin_amdgcn_cvt_pk_u8_f32(fmaf(b, t1 - t0, t0), c, o);
         }
         px[i] = guard[i] ? o : 0u;
     }

@@ -93,6 +93,47 @@ OP2(k_sub_i32_vop3, "v_sub_i32 %0, %0, %1")
 OP2(k_dot4, "v_dot4_i32_i8 %0, %1, %2, %0")
 OP2(k_msad, "v_msad_u8 %0, %0, %1, %2")
 OP2(k_cvt_f32_i32, "v_cvt_f32_i32 %0, %0")
+// the image kernels' ops (round 2): byte -> float, float -> byte, floor / round
+OP2(k_cvt_f32_ubyte0, "v_cvt_f32_ubyte0 %0, %0")
+OP2(k_cvt_f32_ubyte3, "v_cvt_f32_ubyte3 %0, %0")
+OP2(k_rndne_f32, "v_rndne_f32 %0, %0")
+OP2(k_floor_f32, "v_floor_f32 %0, %0")
+OP2(k_fract_f32, "v_fract_f32 %0, %0")
+OP2(k_cvt_i32_f32, "v_cvt_i32_f32 %0, %0")
+OP2(k_cvt_pk_u8_f32, "v_cvt_pk_u8_f32 %0, %1, 1, %0")
+OP2(k_alignbyte, "v_alignbyte_b32 %0, %0, %1, 3")
+#define OP64(name, INSN)                                                                    \
+    __global__ void __launch_bounds__(256) name(unsigned *out, int iters, unsigned seed) {  \
+        double r[8], x = 1.0 + 1e-9 * (seed + threadIdx.x), y = 1e-7 * (seed + threadIdx.x); \
+        unsigned z = seed + threadIdx.x;                                                    \
+        for (int i = 0; i < 8; i++) r[i] = 1.0 + 1e-6 * (seed * (i + 2) + threadIdx.x);     \
+        for (int it = 0; it < iters; it++) {                                                \
+            _Pragma("unroll") for (int u = 0; u < 4; u++) {                                 \
+                _Pragma("unroll") for (int i = 0; i < 8; i++) {                             \
+                    asm volatile(INSN : "+v"(r[i]) : "v"(x), "v"(y), "v"(z));               \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+        double s = 0;                                                                       \
+        for (int i = 0; i < 8; i++) s += r[i];                                              \
+        out[blockIdx.x * 256 + threadIdx.x] = (unsigned)s;                                  \
+    }
+OP64(k_mul_f64, "v_mul_f64 %0, %0, %1")
+OP64(k_add_f64, "v_add_f64 %0, %0, %2")
+OP64(k_fma_f64, "v_fma_f64 %0, %0, %1, %2")
+OP64(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %2")
+OP64(k_pk_add_f32, "v_pk_add_f32 %0, %0, %2")
+OP64(k_lshr_b64, "v_lshrrev_b64 %0, 3, %0")
+OP64(k_cvt_f64_u32, "v_cvt_f64_u32 %0, %3")
+
+__global__ void k_pk_u8_semantics(float *in, unsigned *out, int n) {
+    const int i = threadIdx.x;
+    if (i < n) {
+        unsigned r = 0;
+        asm volatile("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(r) : "v"(in[i]));
+        out[i] = r;
+    }
+}
 
 typedef void (*kern_t)(unsigned *, int, unsigned);
 
@@ -180,6 +221,33 @@ int main() {
     R(k_dot4);
     R(k_msad);
     R(k_cvt_f32_i32);
+    R(k_cvt_f32_ubyte0);
+    R(k_cvt_f32_ubyte3);
+    R(k_rndne_f32);
+    R(k_floor_f32);
+    R(k_fract_f32);
+    R(k_cvt_i32_f32);
+    R(k_cvt_pk_u8_f32);
+    R(k_alignbyte);
+    R(k_mul_f64);
+    R(k_add_f64);
+    R(k_fma_f64);
+    R(k_pk_fma_f32);
+    R(k_pk_add_f32);
+    R(k_lshr_b64);
+    R(k_cvt_f64_u32);
+    {
+        const float h[12] = {0.f, 0.4999f, 0.5f, 0.5001f, 1.5f, 2.5f, 3.5f, 254.5f, 255.4f, 255.5f, 300.f, -1.f};
+        float *din;
+        unsigned ho[12];
+        CK(hipMalloc(&din, sizeof(h)));
+        CK(hipMemcpy(din, h, sizeof(h), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_pk_u8_semantics, dim3(1), dim3(64), 0, 0, din, out, 12);
+        CK(hipMemcpy(ho, out, sizeof(ho), hipMemcpyDeviceToHost));
+        printf("v_cvt_pk_u8_f32 (default rounding mode):");
+        for (int i = 0; i < 12; i++) printf("  %g -> %u", h[i], ho[i]);
+        printf("\n");
+    }
     CK(hipFree(out));
     return 0;
 }
