@@ -280,7 +280,9 @@ template <int C, bool PERSP, bool CLASSIC>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ISX_K1_WAVES))) frame_warp_kernel(const uint8_t *__restrict__ src, const WarpParams P,
                                                           uint8_t *__restrict__ wbuf, int nchunk,
                                                           int32_t *__restrict__ rows, uint64_t *__restrict__ mask) {
-    const int ly = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // (readfirstlane: the wave index is uniform, which the compiler cannot see -- the chunk origin and the extent
+    // bookkeeping below then stay on the scalar unit)
+    const int ly = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     int gl = INT_MAX, gr = -1, l0 = INT_MAX, r0 = -1;
     __shared__ uint64_t mw[(ISX_FRAME_MAX_Q / 256) * 4];
     for (int cw = wave; cw < nchunk; cw += nw) {
@@ -307,7 +309,14 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ISX_K
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             bc[i] = __ballot((px[i] & 255u) != 0u);
-            bg[i] = C == 3 ? __ballot(gray_px<C>(px[i]) != 0) : bc[i];
+            if (C == 3) {
+                // gray != 0 whenever G != 0 (19235 >= 16384, gray3); the exact test only runs if some pixel of the wave
+                // is non-zero with G == 0
+                const uint64_t g = __ballot((px[i] & 0xFF00u) != 0u), nz = __ballot(px[i] != 0u);
+                bg[i] = (nz & ~g) ? __ballot(gray_px<C>(px[i]) != 0) : g;
+            } else {
+                bg[i] = bc[i];
+            }
         }
         const int cx = P.dx0 + chunk * 256;
 #pragma unroll
