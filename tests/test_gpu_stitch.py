@@ -688,3 +688,39 @@ def test_public_stitch_does_not_modify_the_reference_mosaic(cuda, world, tmp_pat
     assert m2.shape[1] > m1.shape[1]
     m1.invalidate()
     assert np.array_equal(np.asarray(m1), before)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("type_", [0, 1])
+def test_sparse_masks_and_narrow_frames_through_the_frame_kernels(cuda, orc, tmp_path, type_):
+    """Stress of the frame kernels' bookkeeping: frames whose channel 0 is zero on about half of the pixels (holes in
+    the per-channel mask, rows whose first and last mask pixel coincide, empty rows and columns, many 0 -> 1
+    transitions per column), frames 2, 3 and 5 pixels wide (the border path's wide loads need 8 bytes per row), and
+    a frame that is one solid row -- each against the oracle pipeline, both blenders."""
+    rng = np.random.default_rng(11)
+    ref = rng.integers(1, 255, (150, 210, 3), dtype=np.uint8)
+    frames, Ms = [ref], []
+
+    def add(f, deg, tx, ty):
+        th = np.deg2rad(deg)
+        c, s = np.cos(th), np.sin(th)
+        frames.append(f)
+        Ms.append([[c, -s, tx], [s, c, ty]] if type_ == 0 else [[c, -s, tx], [s, c, ty], [1e-5, -2e-5, 1.0]])
+
+    f = rng.integers(0, 255, (120, 170, 3), dtype=np.uint8)
+    f[rng.random((120, 170)) < 0.5, 0] = 0            # holes in channel 0 only
+    f[rng.random((120, 170)) < 0.2] = 0               # black pixels
+    f[40:43] = 0                                      # empty rows
+    f[:, 60:62] = 0                                   # empty columns
+    f[70, :] = 0
+    f[70, 33] = (9, 200, 30)                          # a row with exactly one mask pixel (L == R)
+    add(f, 3.0, -20.3, 4.6)
+    for w in (2, 3, 5):
+        add(rng.integers(1, 255, (90, w, 3), dtype=np.uint8), -2.0, 7.5 * w, -3.25)
+    row = np.zeros((40, 120, 3), np.uint8)
+    row[17] = (60, 70, 80)                            # one solid row, everything else black
+    add(row, 0.0, 12.0, 9.0)
+    add(rng.integers(0, 3, (80, 100, 3), dtype=np.uint8), 1.5, -30.2, 20.1)   # gray == 0 almost everywhere
+    for blender in (1, 0):
+        st, _ = _stream_with_given_tf(cuda, tmp_path, frames, Ms, blender, type_=type_)
+        assert st.frame_stats["frames"] == len(Ms)
