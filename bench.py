@@ -204,6 +204,10 @@ def stitch_workload(dev, n_frames):
     cpu_frame_s = time.perf_counter() - t0
     alg_bytes = img.numel() + 2 * roi_px
     executed_bytes = img.numel() + 2 * roi_px + 2 * roi_px  # + the staged warped image, written once and read once
+    frame_traffic = None
+    tf = os.path.join(ROOT, "profiles", "frame_traffic.json")
+    if os.path.exists(tf):  # PMC counters of the three kernels at this frame size (tools/img_bench), collected separately
+        frame_traffic = json.load(open(tf)).get("hbm_bytes_per_frame")
     return {
         "metric": "HD consecutive stitch Hz", "value": k / wall, "unit": "frames/s",
         "frames": k, "stitched": int(ok), "ms_per_frame": wall / k * 1e3,
@@ -224,7 +228,7 @@ def stitch_workload(dev, n_frames):
                                "blender=1 (gradient), binary descriptors matched with L2 as the reference's cv2.BFMatcher() does",
                    "final_mosaic_shape": [int(v) for v in st.refs[-1].shape]},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "frac": alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": frame_traffic,
                      "kernel": "frame_warp_kernel<3,false,false> + frame_extent_kernel + frame_gradient_kernel<3> (the 3 launches "
                                "of one isx_frame_blend call: warp, both bounding boxes, extents, feather blend in place)",
                      "kernel_us": us, "timing": timing, "synchronous_call_us": sync_us, "algorithmic_bytes": int(alg_bytes), "executed_bytes": int(executed_bytes)},

@@ -258,6 +258,15 @@ __device__ __forceinline__ void warp_quad_f32(const uint8_t *__restrict__ src, c
     }
 }
 
+// Row of Q a row workgroup takes.  Workgroup ids go round the 8 XCDs (id % 8); with row = id every XCD's L2 would fetch
+// every source row (a canvas row needs source rows y and y + 1): 2.8 x the frame in memory-side reads, measured with
+// FETCH_SIZE.  Instead XCD x takes the band of rows [x * rpx, (x + 1) * rpx), rpx = ceil(qh / 8): each L2 fetches its
+// band of the frame once.  The grid is 8 * rpx workgroups; the few beyond qh exit.
+__device__ __forceinline__ int frame_row_of_block(int qh) {
+    const int rpx = (qh + 7) >> 3;
+    return (int)(blockIdx.x & 7) * rpx + (int)(blockIdx.x >> 3);
+}
+
 template <int C, bool PERSP, bool CLASSIC>
 __device__ __forceinline__ void warp_quad(const uint8_t *__restrict__ src, const WarpParams &P, int X0, int Y, int n_valid,
                                           uint32_t (&px)[4]) {
@@ -282,7 +291,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ISX_K
                                                           int32_t *__restrict__ rows, uint64_t *__restrict__ mask) {
     // (readfirstlane: the wave index is uniform, which the compiler cannot see -- the chunk origin and the extent
     // bookkeeping below then stay on the scalar unit)
-    const int ly = blockIdx.x, lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int ly = frame_row_of_block(P.dh);
+    if (ly >= P.dh) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     int gl = INT_MAX, gr = -1, l0 = INT_MAX, r0 = -1;
     __shared__ uint64_t mw[(ISX_FRAME_MAX_Q / 256) * 4];
     for (int cw = wave; cw < nchunk; cw += nw) {
@@ -352,7 +363,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ISX_K
             uint64_t word = mw[w];
             if ((unsigned)eL < 256u && (eL & 3) == kk) word &= ~(1ull << (eL >> 2));
             if ((unsigned)eR < 256u && (eR & 3) == kk) word &= ~(1ull << (eR >> 2));
-            mask[((int64_t)chunk * gridDim.x + ly) * 4 + kk] = word;
+            mask[((int64_t)chunk * P.dh + ly) * 4 + kk] = word;
         }
     }
 }
@@ -769,7 +780,9 @@ __global__ void __launch_bounds__(1024) frame_warp_alpha_kernel(const uint8_t *_
                                                                uint8_t *mosaic_q, int64_t mpitch, int nchunk,
                                                                double contrib, double one_minus, int clip_y0, int clip_y1,
                                                                int32_t *__restrict__ rows) {
-    const int ly = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int ly = frame_row_of_block(P.dh);
+    if (ly >= P.dh) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     int gl = INT_MAX, gr = -1, ml = INT_MAX, mr = -1, zeroed = 0, dirty = 0;
     uint8_t *mrow = mosaic_q + (int64_t)ly * mpitch;
     // rows of another strip of the mosaic (another GPU): the warped row still counts for bbox(warped), the mosaic is
@@ -882,6 +895,7 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
     // per SIMD) measured 1 us faster with four waves that take two chunks each at 1080p
     const int max_waves = blender == ISX_BLEND_GRADIENT ? FRAME_MAX_WAVES : 4;
     const int row_threads = 64 * (nchunk < max_waves ? nchunk : max_waves);
+    const int row_blocks = 8 * ((q_h + 7) / 8); // frame_row_of_block()
     const bool persp = model == ISX_MODEL_HOMOGRAPHY, classic = arith == ISX_WARP_CLASSIC;
     int rc;
     WarpParams P;
@@ -897,7 +911,7 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
         if ((rc = ctx_ensure_out(ctx, (size_t)R_INTS + (size_t)6 * n_part)) != ISX_OK) return rc;
         fill_warp_params(P, M_host, model, arith, canvas_w, canvas_h, sh, sw, spitch, src_x, src_y, q_x0, q_y0, q_w, q_h, wpitch);
 #define ISX_FW_LAUNCH(CC, PP, AA)                                                                                \
-    hipLaunchKernelGGL((frame_warp_kernel<CC, PP, AA>), dim3(q_h), dim3(row_threads), 0, st, src_dev, P, ctx->wbuf, \
+    hipLaunchKernelGGL((frame_warp_kernel<CC, PP, AA>), dim3(row_blocks), dim3(row_threads), 0, st, src_dev, P, ctx->wbuf, \
                        nchunk, ctx->rows, ctx->mask)
         if (c == 3) {
             if (persp && classic) ISX_FW_LAUNCH(3, true, true);
@@ -926,7 +940,7 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
         fill_warp_params(P, M_host, model, arith, canvas_w, canvas_h, sh, sw, spitch, src_x, src_y, q_x0, q_y0, q_w, q_h, mpitch);
         const double one_minus = 1 - ref_contrib; // Python: (1-ref_image_contrib)
 #define ISX_FA_LAUNCH(CC, PP, AA)                                                                                     \
-    hipLaunchKernelGGL((frame_warp_alpha_kernel<CC, PP, AA>), dim3(q_h), dim3(row_threads), 0, st, src_dev, P, mosaic_q_dev, \
+    hipLaunchKernelGGL((frame_warp_alpha_kernel<CC, PP, AA>), dim3(row_blocks), dim3(row_threads), 0, st, src_dev, P, mosaic_q_dev, \
                        mpitch, nchunk, ref_contrib, one_minus, clip_y0, clip_y1, ctx->out_dev + R_INTS)
         if (c == 3) {
             if (persp && classic) ISX_FA_LAUNCH(3, true, true);
