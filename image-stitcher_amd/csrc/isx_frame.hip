@@ -578,19 +578,23 @@ template <int C>
 __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__restrict__ wbuf, int64_t wpitch,
                                                              uint8_t *mosaic_q, int64_t mpitch, int qx0, int qy0,
                                                              int qw, int qh, const int32_t *__restrict__ rows,
-                                                             const int32_t *__restrict__ cols, int cstride, int feather,
-                                                             int clip_y0, int clip_y1, const int32_t *__restrict__ res,
-                                                             int32_t *__restrict__ part) {
+                                                             const int32_t *__restrict__ cols, int cstride, int nchunk,
+                                                             int feather, int clip_y0, int clip_y1,
+                                                             const int32_t *__restrict__ res, int32_t *__restrict__ part) {
     constexpr int NW = QuadRaw<C>::N;
     // per-workgroup partial {minx, miny, maxx, maxy, zeroed, dirty} (plain stores, folded on the host)
-    int32_t *mypart = part + 6 * (blockIdx.y * gridDim.x + blockIdx.x);
+    // Tile of this workgroup.  Workgroup ids go round the 8 XCDs (id % 8): XCD x takes the x-th eighth of the tiles in
+    // row-major order, so horizontally adjacent tiles share an L2 (they share 128-byte lines at their edges) and an XCD
+    // blends the band of rows whose warped pixels K1 wrote from the same XCD (frame_row_of_block).  The grid is padded to
+    // a multiple of 8; the workgroups beyond the last tile exit.
+    const int n_tiles = nchunk * ((qh + 4 * G3_IT - 1) / (4 * G3_IT)), per_xcd = (n_tiles + 7) >> 3;
+    const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || tile >= n_tiles) return;
+    int32_t *mypart = part + 6 * tile;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l16 = lane & 15, lr = lane >> 4;
-    // consecutive workgroup ids go to different XCDs (id % 8) and gridDim.x is the number of 256-pixel column chunks,
-    // often 8: without the rotation one XCD would own a whole column of tiles -- e.g. every tile on the frame's left
-    // feather band, the expensive ones
-    const int bx = (int)((blockIdx.x + blockIdx.y) % gridDim.x);
+    const int bx = tile % nchunk, by = tile / nchunk;
     const int lxw = bx * 256 + wave * 64, lx = lxw + 4 * l16, X = qx0 + lx, Xw = qx0 + lxw;
-    const int lyb = blockIdx.y * (4 * G3_IT); // first row of the workgroup
+    const int lyb = by * (4 * G3_IT); // first row of the workgroup
     // every load of the lane is issued before anything depends on the result block (one memory round trip)
     uint32_t dw[G3_IT][NW], dr[G3_IT][NW];
     int L[G3_IT], R[G3_IT];
@@ -901,9 +905,9 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
     WarpParams P;
     if (blender == ISX_BLEND_GRADIENT) {
         const int64_t wpitch = (int64_t)q_w * c;
-        dim3 gb(nchunk, (q_h + 4 * G3_IT - 1) / (4 * G3_IT));
+        const int n_part = nchunk * ((q_h + 4 * G3_IT - 1) / (4 * G3_IT)); // K3's tiles (256 pixels x 4 rows)
+        dim3 gb(8 * ((n_part + 7) / 8));
         const int cstride = (q_w + 3) & ~3;
-        const int n_part = (int)(gb.x * gb.y);
         if ((rc = ctx_ensure(&ctx->wbuf, &ctx->wbuf_cap, (size_t)wpitch * q_h + 16)) != ISX_OK) return rc;
         if ((rc = ctx_ensure(&ctx->rows, &ctx->rows_cap, (size_t)4 * q_h)) != ISX_OK) return rc;
         if ((rc = ctx_ensure(&ctx->cols, &ctx->cols_cap, (size_t)2 * cstride)) != ISX_OK) return rc;
@@ -929,10 +933,10 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
                            canvas_h, 50, ctx->mask, nchunk, ctx->cols, cstride, ctx->out_dev);
         if (c == 3)
             hipLaunchKernelGGL((frame_gradient_kernel<3>), gb, dim3(256), 0, st, ctx->wbuf, wpitch, mosaic_q_dev, mpitch, q_x0,
-                               q_y0, q_w, q_h, ctx->rows, ctx->cols, cstride, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
+                               q_y0, q_w, q_h, ctx->rows, ctx->cols, cstride, nchunk, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
         else
             hipLaunchKernelGGL((frame_gradient_kernel<1>), gb, dim3(256), 0, st, ctx->wbuf, wpitch, mosaic_q_dev, mpitch, q_x0,
-                               q_y0, q_w, q_h, ctx->rows, ctx->cols, cstride, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
+                               q_y0, q_w, q_h, ctx->rows, ctx->cols, cstride, nchunk, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
         ctx->fold_n = n_part;
         ctx->pending = 1;
     } else {
