@@ -443,16 +443,22 @@ __global__ void __launch_bounds__(1024) frame_extent_kernel(const int32_t *__res
             r0max = max(r0max, e.w);
         }
     }
-    {   // one block-wide fold of the six values
+    {   // one block-wide fold of the six values: per wave, then wave 0 folds the 16 wave results (one lane each) and
+        // publishes them -- every thread reading all 16 x 6 partials cost ~100 LDS instructions per wave
         __shared__ int red6[FRAME_MAX_WAVES][6];
+        __shared__ int fin6[6];
         x0 = wave_min(x0), y0 = wave_min(y0), l0min = wave_min(l0min);
         x1 = wave_max(x1), y1 = wave_max(y1), r0max = wave_max(r0max);
         if (lane == 0) red6[k][0] = x0, red6[k][1] = y0, red6[k][2] = l0min, red6[k][3] = x1, red6[k][4] = y1, red6[k][5] = r0max;
         __syncthreads();
-        for (int w = 0; w < FRAME_MAX_WAVES; w++) {
-            x0 = min(x0, red6[w][0]), y0 = min(y0, red6[w][1]), l0min = min(l0min, red6[w][2]);
-            x1 = max(x1, red6[w][3]), y1 = max(y1, red6[w][4]), r0max = max(r0max, red6[w][5]);
+        if (k == 0) {
+            const int w = lane & (FRAME_MAX_WAVES - 1); // (lanes 16..63 repeat entries: harmless for min / max)
+            x0 = wave_min(red6[w][0]), y0 = wave_min(red6[w][1]), l0min = wave_min(red6[w][2]);
+            x1 = wave_max(red6[w][3]), y1 = wave_max(red6[w][4]), r0max = wave_max(red6[w][5]);
+            if (lane == 0) fin6[0] = x0, fin6[1] = y0, fin6[2] = l0min, fin6[3] = x1, fin6[4] = y1, fin6[5] = r0max;
         }
+        __syncthreads();
+        x0 = fin6[0], y0 = fin6[1], l0min = fin6[2], x1 = fin6[3], y1 = fin6[4], r0max = fin6[5];
     }
     const bool found = x1 >= 0;
     const bool first = blockIdx.x == 0 && threadIdx.x == 0;
