@@ -724,3 +724,25 @@ def test_sparse_masks_and_narrow_frames_through_the_frame_kernels(cuda, orc, tmp
     for blender in (1, 0):
         st, _ = _stream_with_given_tf(cuda, tmp_path, frames, Ms, blender, type_=type_)
         assert st.frame_stats["frames"] == len(Ms)
+
+
+@pytest.mark.gpu
+def test_frames_wider_than_16_chunks_and_taller_than_one_extent_batch(cuda, orc, tmp_path):
+    """Geometry limits of the frame kernels' loops: a frame 4500 pixels wide (18 chunks of 256 pixels for the 16 waves of
+    a row workgroup) and a frame 1700 rows tall (two batches of the column-extent hierarchy, 1536 rows each), with
+    black rows / columns inside so that the extents are not trivial; both blenders, against the oracle pipeline."""
+    rng = np.random.default_rng(5)
+    ref = rng.integers(1, 255, (120, 160, 3), dtype=np.uint8)
+    wide = rng.integers(0, 255, (40, 4500, 3), dtype=np.uint8)
+    wide[:, 1000:1003] = 0
+    wide[:, 4200:, 0] = 0                      # channel 0 empty on the right: R of every row far from the gray extent
+    tall = rng.integers(0, 255, (1700, 36, 3), dtype=np.uint8)
+    tall[1535:1540] = 0                        # black rows across the batch boundary
+    tall[:7] = 0
+    th = np.deg2rad(0.4)
+    c, s = np.cos(th), np.sin(th)
+    frames = [ref, wide, tall]
+    Ms = [[[c, -s, 30.5], [s, c, -6.25]], [[c, s, -12.0], [-s, c, 40.75]]]
+    for blender in (1, 0):
+        st, _ = _stream_with_given_tf(cuda, tmp_path, frames, Ms, blender)
+        assert st.frame_stats["frames"] == 2
