@@ -175,8 +175,8 @@ extern "C" int isx_frame_transform(isx_ctx *ctx, const float *src_host, const fl
 // rectangle lands at row off_y, byte off_x of it and everything around it is zeroed (the canvas's padding).
 // *host_out points into the ctx and stays valid until the next call on this ctx that stages data
 // (isx_frame_match / isx_frame_transform / isx_frame_download).
-static int frame_download_impl(isx_ctx *ctx, const uint8_t *src_dev, int64_t spitch, int h, int64_t row_bytes, int out_h,
-                               int64_t out_row_bytes, int off_y, int64_t off_x, const uint8_t **host_out, void *stream, bool sync) {
+extern "C" int isx_frame_download(isx_ctx *ctx, const uint8_t *src_dev, int64_t spitch, int h, int64_t row_bytes, int out_h,
+                                  int64_t out_row_bytes, int off_y, int64_t off_x, const uint8_t **host_out, void *stream) {
     ISX_REQUIRE(ctx && host_out, "null argument");
     ISX_REQUIRE(h >= 0 && row_bytes >= 0 && out_h >= 0 && out_row_bytes >= 0 && off_y >= 0 && off_x >= 0 &&
                     off_y + h <= out_h && off_x + row_bytes <= out_row_bytes,
@@ -200,20 +200,6 @@ static int frame_download_impl(isx_ctx *ctx, const uint8_t *src_dev, int64_t spi
         ISX_HIP_TRY(hipMemcpy2DAsync(D + (size_t)off_y * out_row_bytes + off_x, (size_t)out_row_bytes, src_dev, (size_t)spitch,
                                      (size_t)row_bytes, (size_t)h, hipMemcpyDeviceToDevice, st));
     ISX_HIP_TRY(hipMemcpyAsync(H, D, bytes, hipMemcpyDeviceToHost, st));
-    if (sync) ISX_HIP_TRY(hipStreamSynchronize(st));
+    ISX_HIP_TRY(hipStreamSynchronize(st));
     return ISX_OK;
-}
-
-extern "C" int isx_frame_download(isx_ctx *ctx, const uint8_t *src_dev, int64_t spitch, int h, int64_t row_bytes, int out_h,
-                                  int64_t out_row_bytes, int off_y, int64_t off_x, const uint8_t **host_out, void *stream) {
-    return frame_download_impl(ctx, src_dev, spitch, h, row_bytes, out_h, out_row_bytes, off_y, off_x, host_out, stream, true);
-}
-
-// The same download, only QUEUED on `stream`: the block behind *host_out is complete once the caller has synchronised
-// that stream.  Lets the mosaic region of the next detection travel to the host on a side stream while the new frame is
-// uploaded on the caller's main stream (the two directions of the link are independent).
-extern "C" int isx_frame_download_async(isx_ctx *ctx, const uint8_t *src_dev, int64_t spitch, int h, int64_t row_bytes,
-                                        int out_h, int64_t out_row_bytes, int off_y, int64_t off_x, const uint8_t **host_out,
-                                        void *stream) {
-    return frame_download_impl(ctx, src_dev, spitch, h, row_bytes, out_h, out_row_bytes, off_y, off_x, host_out, stream, false);
 }

@@ -56,8 +56,6 @@ SIGNATURES = {
                                    c_void_p]),
     "isx_frame_download": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_void_p,
                                    c_void_p]),
-    "isx_frame_download_async": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int64, c_int, c_int64, c_void_p,
-                                   c_void_p]),
     "isx_orb_workspace_bytes": (c_int64, [c_int, c_int]),
     "isx_orb_candidates": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p]),

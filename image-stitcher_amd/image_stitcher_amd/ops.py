@@ -523,25 +523,18 @@ def gradient_blend_roi(warped_roi, ref_roi, feather=10, ext=None):
     return ref_roi
 
 
-def frame_download(ctx, img, out_hw=None, offset=(0, 0), side_stream=None):
+def frame_download(ctx, img, out_hw=None, offset=(0, 0)):
     """uint8 device image (possibly a strided view) -> numpy VIEW of the ctx's pinned block holding a contiguous copy
     (one pitched DMA).  out_hw = (H, W) and offset = (y, x): the copy is placed at that position of a zero-filled H x W
     image (a slice of the reference's padded canvas that reaches beyond the mosaic).  Valid until the next
-    frame_match / frame_transform / frame_download on this ctx.
-    side_stream = a torch.cuda.Stream: the download is only QUEUED there (isx_frame_download_async) and the returned
-    view is complete once the caller has synchronised that stream."""
+    frame_match / frame_transform / frame_download on this ctx."""
     p, h, w, c, pitch = _img_args(img)
     oh, ow = (h, w) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
     shape = (oh, ow) + tuple(img.shape[2:])
     out = ctypes.c_void_p()
     with torch.cuda.device(img.device):
-        if side_stream is None:
-            check(_lib.lib().isx_frame_download(ctx._h, p, pitch, h, w * c, oh, ow * c, int(offset[0]), int(offset[1]) * c,
-                                                ctypes.byref(out), _stream()))
-        else:
-            check(_lib.lib().isx_frame_download_async(ctx._h, p, pitch, h, w * c, oh, ow * c, int(offset[0]),
-                                                      int(offset[1]) * c, ctypes.byref(out),
-                                                      ctypes.c_void_p(side_stream.cuda_stream)))
+        check(_lib.lib().isx_frame_download(ctx._h, p, pitch, h, w * c, oh, ow * c, int(offset[0]), int(offset[1]) * c,
+                                            ctypes.byref(out), _stream()))
     n = oh * ow * c
     if n == 0:
         return np.zeros(shape, np.uint8)

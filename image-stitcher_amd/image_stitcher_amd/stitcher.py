@@ -190,7 +190,6 @@ class Stitcher:
         self._pool = None
         self._writer = None
         self._ctx = None          # ops.FrameCtx, created on first use
-        self._dl_stream = None    # side stream of the early mosaic-region download (stitch)
         self._seams_plain_cache = None
         self.phase_seconds = {}   # diagnostics: wall seconds per phase of `stitch`
         self._inplace_ok = False  # set by the internal callers that replace the reference mosaic by the result
@@ -366,10 +365,9 @@ class Stitcher:
         out[oy:oy + img_host.shape[0], ox:ox + img_host.shape[1]] = img_host
         return out
 
-    def _host_region(self, img, ox, oy, H, W, p1, p2, side_stream=None):
+    def _host_region(self, img, ox, oy, H, W, p1, p2):
         """get_roi_from_corners on the padded canvas of `img` (pasted at ox, oy) without building the
-        canvas: numpy slice semantics (clipped to the canvas), zeros outside the image.  side_stream: a download of a
-        resident image is only queued on that stream (the caller synchronises it before reading the result)."""
+        canvas: numpy slice semantics (clipped to the canvas), zeros outside the image."""
         if isinstance(img, DeviceImage) and img._host is not None:
             img = img._host  # the frame came from the host: no download needed
         x0, y0 = max(0, min(W, p1[0])), max(0, min(H, p1[1]))
@@ -382,7 +380,7 @@ class Stitcher:
             if isinstance(img, DeviceImage) and self._seams_plain:
                 # one pitched DMA into the ctx's pinned block; the view is consumed by the detector right away
                 # (before the next staging call on the ctx)
-                return ops.frame_download(self._frame_ctx(), img.t[y0 - oy:y1 - oy, x0 - ox:x1 - ox], side_stream=side_stream)
+                return ops.frame_download(self._frame_ctx(), img.t[y0 - oy:y1 - oy, x0 - ox:x1 - ox])
             return np.asarray(img[y0 - oy:y1 - oy, x0 - ox:x1 - ox])
         ix0, iy0 = max(x0, ox), max(y0, oy)
         ix1, iy1 = min(x1, ox + img.shape[1]), min(y1, oy + img.shape[0])
@@ -390,8 +388,7 @@ class Stitcher:
         if isinstance(img, DeviceImage) and self._seams_plain and x1 > x0 and y1 > y0:
             # the slice reaches beyond the mosaic: zero frame + one pitched DMA of the part that exists, in the ctx
             src = img.t[iy0 - oy:iy1 - oy, ix0 - ox:ix1 - ox] if inter else img.t[0:0, 0:0]
-            return ops.frame_download(self._frame_ctx(), src, (y1 - y0, x1 - x0), (iy0 - y0, ix0 - x0) if inter else (0, 0),
-                                      side_stream=side_stream)
+            return ops.frame_download(self._frame_ctx(), src, (y1 - y0, x1 - x0), (iy0 - y0, ix0 - x0) if inter else (0, 0))
         c = () if img.ndim == 2 else (img.shape[2],)
         out = np.zeros((y1 - y0, x1 - x0) + c, np.uint8)
         if inter:
@@ -580,22 +577,6 @@ class Stitcher:
     def stitch(self, arg_ref, arg_img, tf=None, corners=None):
         tp = time.perf_counter()
         dev = self._dev()
-        ref_early = None
-        if (tf is None and corners is not None and self.consecutive_range is not None and isinstance(arg_ref, DeviceImage)
-                and arg_ref._host is None and isinstance(arg_img, np.ndarray) and self._seams_plain
-                and not getattr(self.algorithm_obj, "accepts_device", False)
-                and not self._overridden("detectAndComputeFromCorners")):
-            # The CPU detector's region of the resident mosaic (stitcher.py:186-188) does not depend on the new frame:
-            # its download is queued on a side stream BEFORE the frame is uploaded, so the two transfers use the two
-            # directions of the link at the same time.  Same bytes as the in-order download below.
-            with torch.cuda.device(dev):
-                if self._dl_stream is None:
-                    self._dl_stream = torch.cuda.Stream(device=dev)
-                self._dl_stream.wait_stream(torch.cuda.current_stream(dev))  # (the mosaic's last writes, e.g. clears)
-                e_ih, e_iw = arg_img.shape[:2]
-                e_rh, e_rw = arg_ref.shape[:2]
-                ref_early = (corners, self._host_region(arg_ref, e_iw, e_ih, e_rh + 2 * e_ih, e_rw + 2 * e_iw, corners[0],
-                                                        corners[1], side_stream=self._dl_stream))
         img_d = DeviceImage.from_any(arg_img, dev)
         ref_d = arg_ref if isinstance(arg_ref, StripMosaic) else DeviceImage.from_any(arg_ref, dev)
         ih, iw = img_d.shape[:2]
@@ -632,12 +613,8 @@ class Stitcher:
                         # a detector that works in HBM gets device views: the mosaic region never visits the host
                         region = self._device_region if dev_det else self._host_region
                         cur_roi = region(img_d, ox, oy, H, W, current_corners[0], current_corners[1])
-                        def ref_roi():
-                            if ref_early is not None and ref_early[0] is corners:
-                                self._dl_stream.synchronize()
-                                return ref_early[1]
-                            return region(ref_d, rox, roy, H, W, corners[0], corners[1])
-                        (kps, thisdes), (rkps, refdes) = self._detect_two(cur_roi, ref_roi)
+                        (kps, thisdes), (rkps, refdes) = self._detect_two(
+                            cur_roi, lambda: region(ref_d, rox, roy, H, W, corners[0], corners[1]))
                         if self._seams_plain:
                             # coordinates only (the keypoint objects do not leave this call): no per-object loops
                             thiskp, refkp = _kp_shifted(kps, current_corners[0]), _kp_shifted(rkps, corners[0])
@@ -656,8 +633,6 @@ class Stitcher:
                     (thiskp, thisdes), (refkp, refdes) = self._detect_two(
                         self._host_canvas(img_d.numpy(), H, W, ox, oy), lambda: self._host_canvas(ref_d.numpy(), H, W, rox, roy))
 
-            if ref_early is not None:
-                self._dl_stream.synchronize()  # (not consumed on every path; the ctx's staging block must be free again)
             tp = self._phase("detect(cpu)+roi_download+kp", tp)
             if refdes is None:
                 self.logger.warning("Key points not found in ref. Moving to next blend.")

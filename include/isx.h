@@ -303,11 +303,6 @@ int isx_frame_transform(isx_ctx *ctx, const float *src_host, const float *dst_ho
  * on this ctx. */
 int isx_frame_download(isx_ctx *ctx, const uint8_t *src_dev, int64_t spitch, int h, int64_t row_bytes, int out_h,
                        int64_t out_row_bytes, int off_y, int64_t off_x, const uint8_t **host_out, void *stream);
-/* isx_frame_download, only queued: the block is complete once the caller has synchronised `stream`.  For overlapping the
- * download of the mosaic region (a side stream) with the upload of the next frame (stitcher.py:159-165, :176-194: the
- * reference does both on the CPU; here they are the two directions of the PCIe link). */
-int isx_frame_download_async(isx_ctx *ctx, const uint8_t *src_dev, int64_t spitch, int h, int64_t row_bytes, int out_h,
-                       int64_t out_row_bytes, int off_y, int64_t off_x, const uint8_t **host_out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * On-GPU ORB-style feature detection.  Stands where the reference calls

@@ -76,15 +76,6 @@ int main() {
             printf("frame: isx_frame_blend %-8s %7.2f us  algorithmic %6.0f GB/s  (wbbox %d,%d-%d,%d roi %d,%d-%d,%d done %d rows_ok %d zeroed %d)\n",
                    blender ? "gradient" : "alpha", t, (src_b + 2 * roi_b) / t / 1e3, res[0], res[1], res[2], res[3], res[5], res[6], res[7], res[8], res[17], res[16], res[14]);
         }
-        {   // the other kernel variants of the gradient chain: homography (type=1), and the classic (<= 4.10) arithmetic
-            const double H[9] = {0.9998, -0.0175, 300.0, 0.0175, 0.9998, 12.0, 1e-6, -2e-6, 1.0};
-            t = time_us(200, [&] { IK(isx_frame_blend(ctx, src, sh, sw, C, sw * C, sx, sy, H, 1, 0, CW, CH, mq, (int64_t)CW * C, dx0, dy0, dw, dh, 0, CH, 1, 0.5, 10, nullptr, 0)); });
-            printf("frame: isx_frame_blend gradient, homography        %7.2f us\n", t);
-            t = time_us(200, [&] { IK(isx_frame_blend(ctx, src, sh, sw, C, sw * C, sx, sy, M, 0, 1, CW, CH, mq, (int64_t)CW * C, dx0, dy0, dw, dh, 0, CH, 1, 0.5, 10, nullptr, 0)); });
-            printf("frame: isx_frame_blend gradient, classic arithmetic %7.2f us\n", t);
-            t = time_us(200, [&] { IK(isx_frame_blend(ctx, src, sh, sw, C, sw * C, sx, sy, H, 1, 1, CW, CH, mq, (int64_t)CW * C, dx0, dy0, dw, dh, 0, CH, 1, 0.5, 10, nullptr, 0)); });
-            printf("frame: isx_frame_blend gradient, homography classic %7.2f us\n", t);
-        }
         t = time_us(50, [&] { IK(isx_frame_blend(ctx, src, sh, sw, C, sw * C, sx, sy, M, 0, 0, CW, CH, mq, (int64_t)CW * C, dx0, dy0, dw, dh, 0, CH, 1, 0.5, 10, res, 0)); });
         printf("frame: isx_frame_blend gradient, synchronous (with result read-back) %7.2f us per call\n", t);
         IK(isx_ctx_destroy(ctx));
