@@ -13,13 +13,18 @@
 //     K1 frame_warp_kernel      one workgroup per canvas row of Q: warped pixels -> staging image, the row's
 //                               gray != 0 extent (-> bbox(warped), stitcher.py:220 / proc.py:194) and channel-0
 //                               extent (-> left/right feather edges, proc.py:213-218), a 1-bit/pixel mask of
-//                               channel 0 != 0; plain stores only, nothing to initialise
+//                               channel 0 != 0 with the row's two edge bits cleared (the feather factor there
+//                               is 0); plain stores only, nothing to initialise
 //     K2 frame_extent_kernel    one workgroup per 256-column chunk: folds the row table into bbox(warped) and
 //                               the ROI (bbox +- 50 px clipped to the canvas, proc.py:199-201); column extents of
-//                               the horizontally feathered mask (proc.py:230-236) by a ballot transpose of the
-//                               bit mask -- one wave owns 64 columns, so no atomics and nothing to initialise
-//     K3 frame_gradient_kernel  feathered blend in place on the mosaic inside the ROI (proc.py:211-253); per-
-//                               workgroup partials of the written pixels' bbox and the zeroed / dirty flags
+//                               the horizontally feathered mask (proc.py:230-236) through a three-level OR
+//                               hierarchy of the bit mask in LDS -- one thread per column and direction, so no
+//                               atomics and nothing to initialise
+//     K3 frame_gradient_kernel  feathered blend in place on the mosaic inside the ROI (proc.py:211-253): a
+//                               byte-parallel select outside the feather bands, the float64 factor chain inside;
+//                               per-workgroup partials of the written pixels' bbox and the zeroed / dirty flags
+//   Row workgroups (K1, alpha) and K3's tiles are dealt to the 8 XCDs in BANDS (frame_row_of_block): each L2 then
+//   fetches its part of the frame / staging image once.
 //   alpha blender (utils/proc.py:48-82)
 //     K1 frame_warp_alpha_kernel  warp + blend in place, per-row table of both bounding boxes and the flags
 //   The small tables (K3's partials / the alpha row table) come back with the result block in ONE device-to-
@@ -368,45 +373,15 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ISX_K
     }
 }
 
-// block-wide min/max of four values; every thread of the block (up to FRAME_MAX_WAVES waves) calls it and gets
-// the result
-__device__ __forceinline__ void block_minmax4(int &a, int &b, int &c, int &d, int (*red)[4]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    a = wave_min(a), b = wave_min(b), c = wave_max(c), d = wave_max(d);
-    __syncthreads(); // red may still be read from a previous call
-    if (lane == 0) red[wave][0] = a, red[wave][1] = b, red[wave][2] = c, red[wave][3] = d;
-    __syncthreads();
-    a = red[0][0], b = red[0][1], c = red[0][2], d = red[0][3];
-    for (int w = 1; w < nw; w++) {
-        a = min(a, red[w][0]);
-        b = min(b, red[w][1]);
-        c = max(c, red[w][2]);
-        d = max(d, red[w][3]);
-    }
-}
-
-__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        lo |= (uint32_t)__shfl_xor((int)lo, m);
-        hi |= (uint32_t)__shfl_xor((int)hi, m);
-    }
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    hi = __builtin_amdgcn_readfirstlane(hi);
-    return ((uint64_t)hi << 32) | lo;
-}
-
 // ------------------------------------------------------------------------------------------------
 // K2 (gradient path).  grid = nchunk workgroups of 1024.  Every workgroup folds the row table (a few KB from L2),
-// so no grid-wide synchronisation is needed; workgroup 0 publishes the result block.  Wave k < 4 of workgroup c
-// then owns the 64 columns 256c + 4i + k (bit i of ballot word k, the layout K1 stores): rows sit on the lanes,
-// and for every column that shows its first (last) set bit in a 64-row group one ballot turns that bit column
-// into a 64-bit row mask whose lowest (highest) set bit is the row.  Each column is visited once per direction.
-// All global loads (row table + this chunk's bit mask) are issued up front, in one round trip: at this size
-// a kernel costs its dependent memory round trips, not its bytes.
+// so no grid-wide synchronisation is needed; workgroup 0 publishes the result block.  The chunk's bit words (the
+// horizontally feathered mask's support: K1 cleared each row's two edge bits) are copied into LDS, OR-ed per 8 and per
+// 64 rows, and eight waves walk the three levels: wave k < 4 finds the top row of the 64 columns 256c + 4i + k (bit i of
+// ballot word k, the layout K1 stores), wave 4 + k the bottom row.  All global loads (row table + this chunk's bit mask)
+// are issued up front, in one round trip: this kernel costs its launch (2.8 us) and the latency of those loads, not its
+// bytes and not its barriers (a variant with half the barriers measured the same, profiles/r02_image_kernels.md).
 // ------------------------------------------------------------------------------------------------
-#define FE_ROWS_PER_THREAD ((FE_BATCH + 1023) / 1024)
 #define FE_PAIRS_PER_THREAD ((FE_BATCH * 2 + 1023) / 1024)
 __global__ void __launch_bounds__(1024) frame_extent_kernel(const int32_t *__restrict__ rows, int qx0, int qy0, int qw,
                                                             int qh, int canvas_w, int canvas_h, int margin,
