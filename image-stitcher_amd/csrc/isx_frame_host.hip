@@ -12,6 +12,7 @@ static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // status_out values of isx_frame_match
 enum { FM_OK = 0, FM_NOT_INTEGER = 1, FM_NORM_LIMIT = 2 };
+#define FM_MAX_SEG 16 // train segments of one pair (header layout below)
 
 extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const void *t_host, int nt, int d, int dtype,
                                int norm, double ratio, int32_t *good_q_out_host, int32_t *good_t_out_host,
@@ -37,19 +38,33 @@ extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const v
     const size_t elem = dtype == ISX_U8 ? 1 : 4;
     // raw rows as uploaded: L2 keeps the caller's width (isx_desc_prep pads), Hamming is padded on the way in
     const size_t raw_row = norm == ISX_NORM_HAMMING ? (size_t)d_pad : (size_t)d * elem;
-    // block layout (device and pinned mirror): [header 256][raw rows][-- device only below --]
-    //   header: isx_knn_item (16) | out_start int64 (8) | count int32 | stats int32[2] | compact count int32
-    const size_t o_raw = 256, o_desc = o_raw + up256(raw_row * rows), o_cbase = o_desc + up256((size_t)d_pad * rows);
+    // One pair on the whole chip: the L2 index kernel takes (query block x train segment) work items -- the train set is
+    // cut into up to FM_MAX_SEG segments of a multiple of 128 rows (the kernel's staging chunk) and the per-segment
+    // results are merged in the compaction kernel (isx_ratio_compact_segments).  With query blocks alone a 1500 x 1500
+    // pair runs on 6 workgroups that each scan every train row (22 us, latency-bound).
+    int n_seg = 1, seg_rows = nt;
+    if (norm == ISX_NORM_L2) {
+        seg_rows = 128 * ((nt + 128 * FM_MAX_SEG - 1) / (128 * FM_MAX_SEG));
+        n_seg = (nt + seg_rows - 1) / seg_rows;
+    }
+    // block layout (device and pinned mirror): [header 512][raw rows][-- device only below --]
+    //   header: isx_knn_item[16] (256) | out_start int64[16] (128) | count int32[16] (64) | stats int32[2] | compact count int32
+    const size_t o_raw = 512, o_desc = o_raw + up256(raw_row * rows), o_cbase = o_desc + up256((size_t)d_pad * rows);
     const size_t o_nrm = o_cbase + up256(4 * (size_t)rows), o_cin = o_nrm + up256(4 * (size_t)rows);
-    const size_t o_idx = o_cin + up256(4 * (size_t)rows), o_dist = o_idx + up256(8 * (size_t)nq);
-    const size_t o_out = o_dist + up256(8 * (size_t)nq); // read-back region: [hdr copy 64][good_q nq][good_t nq]
+    const size_t o_idx = o_cin + up256(4 * (size_t)rows), o_dist = o_idx + up256(8 * (size_t)nq * n_seg);
+    const size_t o_out = o_dist + up256(8 * (size_t)nq * n_seg); // read-back region: [hdr copy 64][good_q nq][good_t nq]
     const size_t o_gq = o_out + 64, o_gt = o_gq + 4 * (size_t)nq, total = o_gt + 4 * (size_t)nq + 256;
     int rc = ctx_ensure_staging(ctx, total);
     if (rc != ISX_OK) return rc;
     uint8_t *H = ctx->hs_host, *D = ctx->hs_dev;
-    memset(H, 0, 256);
+    memset(H, 0, 512);
     isx_knn_item *item = (isx_knn_item *)H;
-    item->q_start = 0, item->nq = nq, item->t_start = nq, item->nt = nt;
+    int64_t *out_start_h = (int64_t *)(H + 256);
+    for (int sg = 0; sg < n_seg; sg++) {
+        item[sg].q_start = 0, item[sg].nq = nq, item[sg].t_start = nq + sg * seg_rows;
+        item[sg].nt = nt - sg * seg_rows < seg_rows ? nt - sg * seg_rows : seg_rows;
+        out_start_h[sg] = (int64_t)sg * nq;
+    }
     if (norm == ISX_NORM_HAMMING && d != d_pad) {
         memset(H + o_raw, 0, raw_row * rows);
         for (int r = 0; r < nq; r++) memcpy(H + o_raw + raw_row * r, (const uint8_t *)q_host + (size_t)d * r, d);
@@ -60,8 +75,8 @@ extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const v
     }
     ISX_HIP_TRY(hipMemcpyAsync(D, H, o_raw + raw_row * rows, hipMemcpyHostToDevice, st));
     const isx_knn_item *items_dev = (const isx_knn_item *)D;
-    const int64_t *out_start_dev = (const int64_t *)(D + 16);
-    int32_t *count_dev = (int32_t *)(D + 24), *stats_dev = (int32_t *)(D + 28), *ccount_dev = (int32_t *)(D + 36);
+    const int64_t *out_start_dev = (const int64_t *)(D + 256);
+    int32_t *count_dev = (int32_t *)(D + 384), *stats_dev = (int32_t *)(D + 448), *ccount_dev = (int32_t *)(D + 456);
     int32_t *idx_dev = (int32_t *)(D + o_idx);
     float *dist_dev = (float *)(D + o_dist);
     if (norm == ISX_NORM_HAMMING) {
@@ -71,17 +86,18 @@ extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const v
                            (int32_t *)(D + o_cin), stats_dev, st);
         if (rc != ISX_OK) return rc;
         rc = isx_knn2_l2_items((const int8_t *)(D + o_desc), (const uint32_t *)(D + o_cbase), (const int32_t *)(D + o_nrm), d_pad,
-                               items_dev, 1, nq, ratio, idx_dev, dist_dev, out_start_dev, count_dev, st);
+                               items_dev, n_seg, nq, ratio, idx_dev, dist_dev, out_start_dev, count_dev, st);
     }
     if (rc != ISX_OK) return rc;
-    rc = isx_ratio_compact(idx_dev, dist_dev, nq, ratio, (int32_t *)(D + o_gq), (int32_t *)(D + o_gt), ccount_dev, st);
+    rc = isx_ratio_compact_segments(idx_dev, dist_dev, nq, n_seg, seg_rows, ratio, (int32_t *)(D + o_gq), (int32_t *)(D + o_gt),
+                                    ccount_dev, st);
     if (rc != ISX_OK) return rc;
-    // one read-back: header (counts, stats) + both index lists
-    ISX_HIP_TRY(hipMemcpyAsync(D + o_out, D, 64, hipMemcpyDeviceToDevice, st));
+    // one read-back: header tail (stats, compaction count) + both index lists
+    ISX_HIP_TRY(hipMemcpyAsync(D + o_out, D + 448, 64, hipMemcpyDeviceToDevice, st));
     ISX_HIP_TRY(hipMemcpyAsync(H + o_out, D + o_out, 64 + 8 * (size_t)nq, hipMemcpyDeviceToHost, st));
     ISX_HIP_TRY(hipStreamSynchronize(st));
     const int32_t *hdr = (const int32_t *)(H + o_out);
-    const int32_t stats0 = hdr[7], stats1 = hdr[8], g = hdr[9];
+    const int32_t stats0 = hdr[0], stats1 = hdr[1], g = hdr[2];
     *status_out = FM_OK;
     *n_good_out = 0;
     if (norm == ISX_NORM_L2) {

@@ -1325,8 +1325,15 @@ extern "C" int isx_knn2_hamming_count_fp4(const uint8_t *desc_dev, const int32_t
 // (reference stitcher.py:118-127) as a list, in query order.  One workgroup walks the rows in chunks
 // of 1024 with a ballot/popcount prefix sum, so the output order equals the reference's append order.
 // ------------------------------------------------------------------------------------------------
+// n_seg > 1: idx / dist hold n_seg kNN-2 results of the SAME queries against consecutive segments of seg_rows train
+// rows each (result s at entry offset s * nq * 2, indices relative to its segment); they are merged per query first.
+// The global two nearest rows are the two smallest of the union of the per-segment pairs under (distance, train index)
+// -- distances are float32 square roots of integers, equal integers give equal floats, and cv2 keeps the lower train
+// index on a tie, within a segment (the kernel's rule) and therefore across segments too.
+#define RC_MAX_SEG 16
 __global__ void __launch_bounds__(1024) ratio_compact_kernel(const int32_t *__restrict__ idx,
                                                              const float *__restrict__ dist, int nq, double ratio,
+                                                             int n_seg, int seg_rows,
                                                              int32_t *__restrict__ good_q,
                                                              int32_t *__restrict__ good_t,
                                                              int32_t *__restrict__ count_out) {
@@ -1340,9 +1347,34 @@ __global__ void __launch_bounds__(1024) ratio_compact_kernel(const int32_t *__re
         bool good = false;
         int t0 = -1;
         if (i < nq) {
-            t0 = idx[2 * i];
-            const int t1 = idx[2 * i + 1];
-            if (t0 >= 0) good = t1 < 0 || (double)dist[2 * i] < ratio * (double)dist[2 * i + 1];
+            // (all segments' pairs are fetched before the first compare: one memory round trip instead of n_seg)
+            int2 js[RC_MAX_SEG];
+            float2 ds[RC_MAX_SEG];
+#pragma unroll
+            for (int sg = 0; sg < RC_MAX_SEG; sg++) {
+                const int64_t o = (int64_t)(sg < n_seg ? sg : 0) * nq + i;
+                js[sg] = ((const int2 *)idx)[o];
+                ds[sg] = ((const float2 *)dist)[o];
+            }
+            t0 = js[0].x;
+            int t1 = js[0].y;
+            float d0 = ds[0].x, d1 = ds[0].y;
+#pragma unroll
+            for (int sg = 1; sg < RC_MAX_SEG; sg++) { // (segments in index order: a later candidate only wins if strictly nearer)
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int j = e ? js[sg].y : js[sg].x;
+                    if (sg >= n_seg || j < 0) continue; // (no break: the arrays stay in registers, statically indexed)
+                    const int jg = sg * seg_rows + j;
+                    const float dj = e ? ds[sg].y : ds[sg].x;
+                    if (t0 < 0 || dj < d0) {
+                        t1 = t0, d1 = d0, t0 = jg, d0 = dj;
+                    } else if (t1 < 0 || dj < d1) {
+                        t1 = jg, d1 = dj;
+                    }
+                }
+            }
+            if (t0 >= 0) good = t1 < 0 || (double)d0 < ratio * (double)d1;
         }
         const unsigned long long b = __ballot(good);
         const int before = __popcll(b & ((1ull << lane) - 1ull));
@@ -1371,7 +1403,19 @@ extern "C" int isx_ratio_compact(const int32_t *idx_dev, const float *dist_dev, 
     ISX_REQUIRE(nq >= 0, "negative nq");
     ISX_REQUIRE(count_out_dev, "null count_out_dev");
     ISX_REQUIRE(nq == 0 || (idx_dev && dist_dev && good_q_out_dev && good_t_out_dev), "null device pointer");
-    hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx_dev, dist_dev, nq, ratio,
+    hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx_dev, dist_dev, nq, ratio, 1, 0,
                        good_q_out_dev, good_t_out_dev, count_out_dev);
+    return isx_launch_status("ratio_compact_kernel");
+}
+
+extern "C" int isx_ratio_compact_segments(const int32_t *idx_dev, const float *dist_dev, int nq, int n_seg, int seg_rows,
+                                          double ratio, int32_t *good_q_out_dev, int32_t *good_t_out_dev,
+                                          int32_t *count_out_dev, void *stream) {
+    ISX_REQUIRE(nq >= 0 && n_seg >= 1 && n_seg <= RC_MAX_SEG && seg_rows >= 0, "bad sizes (1 <= n_seg <= %d)", RC_MAX_SEG);
+    ISX_REQUIRE((((uintptr_t)idx_dev | (uintptr_t)dist_dev) & 7) == 0, "idx_dev / dist_dev must be 8-byte aligned");
+    ISX_REQUIRE(count_out_dev, "null count_out_dev");
+    ISX_REQUIRE(nq == 0 || (idx_dev && dist_dev && good_q_out_dev && good_t_out_dev), "null device pointer");
+    hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx_dev, dist_dev, nq, ratio, n_seg,
+                       seg_rows, good_q_out_dev, good_t_out_dev, count_out_dev);
     return isx_launch_status("ratio_compact_kernel");
 }

@@ -40,6 +40,8 @@ SIGNATURES = {
     "isx_knn2_f32_items": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
     "isx_ratio_compact": (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "isx_ratio_compact_segments": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]),
     "isx_bbox_nonzero": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),
     "isx_bbox_reset": (c_int, [c_void_p, c_void_p]),
     "isx_bbox_nonzero_static": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p]),

@@ -154,6 +154,13 @@ int isx_knn2_f32_items(const float *desc_dev, const float *nrm_dev, int d, const
  * good_q/good_t: nq int32 each (capacity); count_out_dev: 1 int32 = len(good_matches). */
 int isx_ratio_compact(const int32_t *idx_dev, const float *dist_dev, int nq, double ratio,
                       int32_t *good_q_out_dev, int32_t *good_t_out_dev, int32_t *count_out_dev, void *stream);
+/* The same list from a kNN-2 result computed in n_seg pieces: result s (entry offset s * nq * 2) holds the two nearest
+ * rows of train segment s = rows [s * seg_rows, (s + 1) * seg_rows) with indices relative to the segment; the pieces
+ * are merged per query under (distance, train index), which is BFMatcher's order (stitcher.py:106-116), and the list
+ * is built as above (n_seg <= 16; idx_dev / dist_dev 8-byte aligned).  Lets one image pair spread over the whole chip: isx_frame_match runs the index kernel on
+ * (query block x train segment) work items instead of query blocks only. */
+int isx_ratio_compact_segments(const int32_t *idx_dev, const float *dist_dev, int nq, int n_seg, int seg_rows, double ratio,
+                               int32_t *good_q_out_dev, int32_t *good_t_out_dev, int32_t *count_out_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Image space.  All images: uint8, interleaved channels (c = 1 or 3), PITCHED: `pitch` is the row

@@ -246,3 +246,33 @@ def test_item_lists_longer_than_one_grid(cuda, orc):
         assert np.array_equal(idx[s:s + ct[qi[e]]].cpu().numpy(), ridx)
         assert np.array_equal(dist[s:s + ct[qi[e]]].cpu().numpy(), rdist)
     assert exp.min() == 0 and exp.max() >= 3
+
+
+@pytest.mark.parametrize("nq,nt,d", [(700, 1500, 32), (300, 130, 128), (257, 3000, 61), (5, 1, 32), (64, 128, 32), (1500, 2049, 32)])
+def test_frame_match_train_segments_merge_exactly(cuda, orc, nq, nt, d):
+    """isx_frame_match runs the index kernel on (query block x train segment) items and merges the per-segment results
+    in the compaction kernel: the good-match list must be the oracle's (knn2 + ratio loop), including ties whose two
+    rows lie in different segments (the lower train index wins, as in cv2) and queries whose two nearest rows come
+    from two different segments."""
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(nq + 3 * nt + d)
+    t = rng.integers(0, 150, (nt, d), dtype=np.uint8)
+    q = rng.integers(0, 150, (nq, d), dtype=np.uint8)
+    if nt > 400:
+        # queries copied from train rows with a little noise (so that the ratio test passes for them), and duplicated
+        # train rows 128, 256 ... rows apart: exact ties across segment boundaries
+        src = rng.permutation(nt)[:nq // 2]
+        q[:len(src)] = np.clip(t[src].astype(np.int16) + rng.integers(-2, 3, (len(src), d)), 0, 255).astype(np.uint8)
+        for a, b in [(3, 131), (10, 266), (127, 128), (40, nt - 1), (300, 301), (5, 389)]:
+            t[b] = t[a]
+        q[-6:] = t[[3, 10, 127, 40, 300, 5]]
+    ctx = ops.FrameCtx("cuda:0")
+    for ratio in (0.65, 0.9, 1.0):
+        gq, gt = ops.frame_match(ctx, q, t, ratio)
+        ridx, rdist = orc.knn2(q, t)
+        oq, ot = orc.ratio_filter(ridx, rdist, ratio)
+        assert np.array_equal(gq, oq) and np.array_equal(gt, ot), (ratio, len(gq), len(oq))
+    # float32 input (integer valued, as cv2.SIFT returns) takes the same path
+    gq, gt = ops.frame_match(ctx, q.astype(np.float32), t.astype(np.float32), 0.8)
+    oq, ot = orc.ratio_filter(*orc.knn2(q, t), 0.8)
+    assert np.array_equal(gq, oq) and np.array_equal(gt, ot)
