@@ -563,6 +563,45 @@ extern "C" int isx_gradient_blend(const uint8_t *warped_dev, int64_t wpitch, uin
 }
 
 // pitched device-to-device copy used by the mosaic arena
+// Zero up to four byte rectangles of a pitched image in ONE launch (blockIdx.y = rectangle).
+struct ClearRects {
+    int32_t r[4][4]; // {row0, row1, byte0, byte1} per rectangle
+};
+__global__ void __launch_bounds__(256) clear_rects_kernel(uint8_t *__restrict__ dst, int64_t pitch, const ClearRects R) {
+    const int y0 = R.r[blockIdx.y][0], y1 = R.r[blockIdx.y][1], b0 = R.r[blockIdx.y][2], b1 = R.r[blockIdx.y][3];
+    for (int y = y0 + blockIdx.x; y < y1; y += gridDim.x) {
+        uint8_t *row = dst + (int64_t)y * pitch;
+        // bytes up to the first 4-byte boundary and after the last one singly, dwords in between
+        const int a0 = min(b1, b0 + (int)((4 - ((uintptr_t)(row + b0) & 3)) & 3)), a1 = a0 + ((b1 - a0) & ~3);
+        for (int b = b0 + threadIdx.x; b < a0; b += 256) row[b] = 0;
+        for (int b = a0 + 4 * threadIdx.x; b < a1; b += 1024) *(uint32_t *)(row + b) = 0u;
+        for (int b = a1 + threadIdx.x; b < b1; b += 256) row[b] = 0;
+    }
+}
+
+extern "C" int isx_clear_rects(uint8_t *dst_dev, int64_t dpitch, int h, int64_t row_bytes, const int32_t *rects_host, int n,
+                               void *stream) {
+    ISX_REQUIRE(n >= 0 && n <= 4, "at most four rectangles per call (got %d)", n);
+    if (n == 0) return ISX_OK;
+    ISX_REQUIRE(dst_dev && rects_host && h >= 0 && row_bytes >= 0 && dpitch >= row_bytes && row_bytes < ((int64_t)1 << 31),
+                "bad clear_rects arguments");
+    ClearRects R;
+    int rows = 0;
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 4; k++) R.r[i][k] = 0;
+    for (int i = 0; i < n; i++) {
+        const int32_t *q = rects_host + 4 * i;
+        ISX_REQUIRE(q[0] >= 0 && q[0] <= q[1] && q[1] <= h && q[2] >= 0 && q[2] <= q[3] && q[3] <= row_bytes,
+                    "rectangle %d = rows %d..%d, bytes %d..%d outside the %d x %lld image", i, q[0], q[1], q[2], q[3], h,
+                    (long long)row_bytes);
+        for (int k = 0; k < 4; k++) R.r[i][k] = q[k];
+        rows = rows > q[1] - q[0] ? rows : q[1] - q[0];
+    }
+    if (rows == 0) return ISX_OK;
+    hipLaunchKernelGGL(clear_rects_kernel, dim3(rows < 512 ? rows : 512, n), dim3(256), 0, (hipStream_t)stream, dst_dev, dpitch, R);
+    return isx_launch_status("clear_rects_kernel");
+}
+
 extern "C" int isx_copy2d(const uint8_t *src_dev, int64_t spitch, uint8_t *dst_dev, int64_t dpitch, int h,
                           int64_t row_bytes, void *stream) {
     ISX_REQUIRE(h >= 0 && row_bytes >= 0, "negative size");

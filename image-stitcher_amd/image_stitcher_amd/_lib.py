@@ -75,6 +75,7 @@ SIGNATURES = {
     "isx_frame_result": (c_int, [c_void_p, c_void_p, c_void_p]),
     "isx_frame_warped": (c_int, [c_void_p, c_void_p]),
     "isx_copy2d": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "isx_clear_rects": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_int, c_void_p]),
     "isx_ransac_sample": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "isx_ransac_hypotheses": (c_int, [c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "isx_ransac_score": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p,

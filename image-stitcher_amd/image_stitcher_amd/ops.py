@@ -413,6 +413,18 @@ def bbox_nonzero(img, acc=None):
     return acc[:5]
 
 
+def clear_rects(img, rects):
+    """Zero up to four rectangles (y0, y1, x0, x1) (half-open, pixels) of a uint8 device image in one launch."""
+    rects = [r for r in rects if r[1] > r[0] and r[3] > r[2]]
+    if not rects:
+        return 0
+    p, h, w, c, pitch = _img_args(img)
+    a = np.array([(r[0], r[1], r[2] * c, r[3] * c) for r in rects], np.int32)
+    with torch.cuda.device(img.device):
+        check(_lib.lib().isx_clear_rects(p, pitch, h, w * c, a.ctypes.data_as(ctypes.c_void_p), len(rects), _stream()))
+    return len(rects)
+
+
 def bbox_to_corners(bb_host):
     """numpy int32[5] -> ((x0,y0),(x1,y1)) or False, the reference's get_corners_from_image contract."""
     if not bb_host[4]:

@@ -19,6 +19,7 @@ Deliberate differences from the reference:
 import copy
 import logging
 import os
+import math
 import time
 
 import numpy as np
@@ -420,18 +421,26 @@ class Stitcher:
 
     def _quad_region(self, M, ox, oy, iw, ih, W, H, margin):
         """Conservative canvas rectangle that contains every non-zero pixel of the warped frame."""
-        pts = np.array([[ox - 1, oy - 1, 1], [ox + iw, oy - 1, 1], [ox + iw, oy + ih, 1], [ox - 1, oy + ih, 1]], np.float64)
-        Mh = np.vstack([M, [0, 0, 1]]) if M.shape[0] == 2 else M
-        q = pts @ Mh.T
-        if not np.all(np.isfinite(q)) or np.any(q[:, 2] <= 1e-9):
-            return 0, 0, W, H
-        xy = q[:, :2] / q[:, 2:3]
-        if not np.all(np.isfinite(xy)) or np.abs(xy).max() > 1e8:
-            return 0, 0, W, H
-        x0 = int(np.floor(xy[:, 0].min())) - 2 - margin
-        y0 = int(np.floor(xy[:, 1].min())) - 2 - margin
-        x1 = int(np.ceil(xy[:, 0].max())) + 3 + margin
-        y1 = int(np.ceil(xy[:, 1].max())) + 3 + margin
+        # (plain Python floats: four points do not pay for numpy's per-call overhead)
+        m = [[float(v) for v in row] for row in M]
+        if len(m) == 2:
+            m.append([0.0, 0.0, 1.0])
+        xs, ys = [], []
+        for px, py in ((ox - 1, oy - 1), (ox + iw, oy - 1), (ox + iw, oy + ih), (ox - 1, oy + ih)):
+            qx = m[0][0] * px + m[0][1] * py + m[0][2]
+            qy = m[1][0] * px + m[1][1] * py + m[1][2]
+            qw = m[2][0] * px + m[2][1] * py + m[2][2]
+            if not (math.isfinite(qx) and math.isfinite(qy) and math.isfinite(qw)) or qw <= 1e-9:
+                return 0, 0, W, H
+            x, y = qx / qw, qy / qw
+            if not (math.isfinite(x) and math.isfinite(y)) or abs(x) > 1e8 or abs(y) > 1e8:
+                return 0, 0, W, H
+            xs.append(x)
+            ys.append(y)
+        x0 = int(math.floor(min(xs))) - 2 - margin
+        y0 = int(math.floor(min(ys))) - 2 - margin
+        x1 = int(math.ceil(max(xs))) + 3 + margin
+        y1 = int(math.ceil(max(ys))) + 3 + margin
         return max(0, x0), max(0, y0), min(W, x1), min(H, y1)
 
     @property
@@ -533,11 +542,8 @@ class Stitcher:
             return None, wcorners
         if arena.dirty or res["dirty"] or rescan or res["zeroed"]:
             # bytes of gray == 0 pixels outside the crop: the reference's crop drops them
-            for (y0, y1, x0, x1) in ((uy0, new[1], ux0, ux1), (new[3], uy1, ux0, ux1), (new[1], new[3], ux0, new[0]),
-                                     (new[1], new[3], new[2], ux1)):
-                if y1 > y0 and x1 > x0:
-                    arena.t[y0:y1, x0:x1] = 0
-                    self.frame_stats["clears"] += 1
+            self.frame_stats["clears"] += ops.clear_rects(arena.t, ((uy0, new[1], ux0, ux1), (new[3], uy1, ux0, ux1),
+                                                                     (new[1], new[3], ux0, new[0]), (new[1], new[3], new[2], ux1)))
         arena.x, arena.y, arena.w, arena.h = new[0], new[1], new[2] - new[0], new[3] - new[1]
         arena.bbox, arena.dirty = new, False
         return DeviceImage(arena.view(), arena=arena), wcorners
@@ -588,8 +594,19 @@ class Stitcher:
         W, H = rw + 2 * iw, rh + 2 * ih
         rox, roy = iw, ih
         ox, oy = (rw + iw) // 2, (rh + ih) // 2
-        with torch.cuda.device(dev):
-            bb = ops.bbox_nonzero(img_d.t).cpu().numpy()
+        bb = None
+        host = img_d._host
+        if host is not None and ih > 0 and iw > 0:
+            # get_corners_from_image of the frame (stitcher.py:178-179): when each of the four border lines holds a pixel
+            # with gray != 0 the box is the whole frame, and the host copy can tell (G != 0 implies gray != 0: its weight
+            # alone, 19235, exceeds the rounding threshold 16384; for one channel the byte is the gray value) -- no
+            # kernel, no read-back.  Any other frame goes to the device.
+            g = host if host.ndim == 2 else (host[:, :, 1] if host.shape[2] == 3 else None)
+            if g is not None and g[0].any() and g[ih - 1].any() and g[:, 0].any() and g[:, iw - 1].any():
+                bb = (0, 0, iw, ih, 1)
+        if bb is None:
+            with torch.cuda.device(dev):
+                bb = ops.bbox_nonzero(img_d.t).cpu().numpy()
         if bb[4]:
             current_corners = ((int(bb[0]) + ox, int(bb[1]) + oy), (int(bb[2]) + ox, int(bb[3]) + oy))
         else:

@@ -232,6 +232,10 @@ int isx_gradient_blend(const uint8_t *warped_dev, int64_t wpitch, uint8_t *ref_d
 /* Pitched device-to-device copy (mosaic arena growth / get_padded_images paste, utils/proc.py:290-291). */
 int isx_copy2d(const uint8_t *src_dev, int64_t spitch, uint8_t *dst_dev, int64_t dpitch, int h,
                int64_t row_bytes, void *stream);
+/* Zero up to four rectangles {row0, row1, byte0, byte1} (half-open, rects_host = 4 int32 each, HOST memory) of a pitched
+ * image in one launch: the strips between the merged canvas's crop (stitcher.py:225, utils/proc.py:307-312 drops them)
+ * and what the blend wrote on a resident mosaic arena. */
+int isx_clear_rects(uint8_t *dst_dev, int64_t dpitch, int h, int64_t row_bytes, const int32_t *rects_host, int n, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-frame pipeline on a resident mosaic.  Replaces, in one call, the tail of Stitcher.stitch
