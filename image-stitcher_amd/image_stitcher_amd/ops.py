@@ -9,7 +9,14 @@ from . import _lib
 from ._lib import IsxError, NormLimitError, NotIntegerValuedError, check
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Raw handle of the current stream of the current device.  (torch.cuda.current_stream() builds a Stream object and
+    resolves the device index in Python -- 8-10 us per call, five calls per stitched frame.)"""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -50,4 +50,4 @@ pr.enable()
 run()
 pr.disable()
 ps = pstats.Stats(pr)
-ps.sort_stats("tottime").print_stats(32)
+ps.sort_stats("cumulative").print_stats(45)
