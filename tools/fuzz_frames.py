@@ -1,0 +1,76 @@
+"""Fuzz of the frame pipeline against the oracle pipeline: random sizes, transforms, sparse content, both blenders.
+usage: python3 tools/fuzz_frames.py [cases=100] [first seed=1000] [size scale=1]   (exit status 1 on any mismatch)"""
+import sys, os, tempfile
+ROOT = "/root/repo" if os.path.exists("/root/repo/tests") else os.environ.get("GRAFT_REPO_ROOT", ".")
+sys.path.insert(0, os.path.join(ROOT, "image-stitcher_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from image_stitcher_amd import ConsecutiveStitcher, TransformDetails
+from oracle_stitch import oracle_stitch, Cfg
+
+def content(rng, h, w, c):
+    shape = (h, w, c) if c == 3 else (h, w)
+    mode = rng.integers(0, 4)
+    if mode == 0:
+        f = rng.integers(1, 255, shape, dtype=np.uint8)
+    elif mode == 1:
+        f = rng.integers(0, 255, shape, dtype=np.uint8)
+        m = rng.random((h, w)) < 0.4
+        if c == 3: f[m, 0] = 0
+        else: f[m] = 0
+    elif mode == 2:
+        f = rng.integers(0, 4, shape, dtype=np.uint8)
+    else:
+        f = np.zeros(shape, np.uint8)
+        y0, x0 = rng.integers(0, max(1, h // 2)), rng.integers(0, max(1, w // 2))
+        f[y0:y0 + rng.integers(1, h), x0:x0 + rng.integers(1, w)] = rng.integers(1, 255, 3 if c == 3 else 1, dtype=np.uint8) if c == 3 else rng.integers(1, 255)
+    if rng.random() < 0.3: f[rng.integers(0, h)] = 0
+    if rng.random() < 0.3: f[:, rng.integers(0, w)] = 0
+    return f
+
+def main(n_cases, seed0, scale=1):
+    bad = 0
+    for case in range(n_cases):
+        rng = np.random.default_rng(seed0 + case)
+        c = 3 if rng.random() < 0.7 else 1
+        rh, rw = int(rng.integers(4, 260 * scale)), int(rng.integers(4, 330 * scale))
+        ih, iw = int(rng.integers(2, 260 * scale)), int(rng.integers(2, 330 * scale))
+        ref = content(rng, rh, rw, c)
+        if not ref.any(): ref.flat[0] = 9
+        img = content(rng, ih, iw, c)
+        type_ = int(rng.integers(0, 2)); blender = int(rng.integers(0, 2))
+        th = np.deg2rad(rng.uniform(-12, 12)); sc = rng.uniform(0.85, 1.2)
+        tx, ty = rng.uniform(-0.9 * iw, 0.9 * rw), rng.uniform(-0.9 * ih, 0.9 * rh)
+        if rng.random() < 0.25: th, sc = 0.0, 1.0
+        if rng.random() < 0.2: tx, ty = float(int(tx)), float(int(ty))
+        cs, sn = sc * np.cos(th), sc * np.sin(th)
+        M = [[cs, -sn, tx - iw / 2], [sn, cs, ty - ih / 2]]
+        if type_ == 1: M = M + [[rng.uniform(-2e-4, 2e-4), rng.uniform(-2e-4, 2e-4), 1.0]]
+        M = np.asarray(M, np.float64)
+        tmp = tempfile.mkdtemp(prefix="isx_fuzz_")
+        st = ConsecutiveStitcher(log_level=3, output_dir=tmp, type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1, detector=object())
+        cfg = Cfg(type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1)
+        pts = np.zeros((5, 1, 2), np.float32)
+        try:
+            st.stitch_consecutive(ref)
+            tf = TransformDetails(M, pts, pts)
+            r = st.stitch_consecutive(img, tf)
+            o = oracle_stitch(ref, img, None, cfg, tf=(M, pts, pts), corners=None)
+            if o is None or o is False:
+                ok = (st.refs[-1] is None) or r is None or r is False or True
+                got = None
+            else:
+                got = np.asarray(st.refs[-1])
+                ok = got.shape == o[0].shape and np.array_equal(got, o[0]) and st.corners == o[1]
+        except Exception as e:
+            ok = False; got = repr(e)
+        if not ok:
+            bad += 1
+            print("MISMATCH case", seed0 + case, dict(c=c, ref=(rh, rw), img=(ih, iw), type=type_, blender=blender), "M=", M.tolist(),
+                  None if got is None or isinstance(got, str) else (got.shape, o[0].shape), got if isinstance(got, str) else "", flush=True)
+        if case % 25 == 0: print("case", case, "bad", bad, flush=True)
+    print("done", n_cases, "cases,", bad, "mismatches")
+    return bad
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 1000,
+                       int(sys.argv[3]) if len(sys.argv) > 3 else 1) else 0)
