@@ -15,3 +15,11 @@ def test_fuzz_frames_against_the_oracle(cuda, orc):
     import fuzz_frames
     assert fuzz_frames.main(150, 31000) == 0
     assert fuzz_frames.main(12, 32000, 5) == 0
+
+
+def test_fuzz_frame_match_against_the_oracle(cuda, orc):
+    """tools/fuzz_match.py: isx_frame_match (train segments merged per query) against the oracle's knnMatch + ratio loop
+    on random sizes, widths and value ranges with many exact ties."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz_match
+    assert fuzz_match.main(60) == 0
