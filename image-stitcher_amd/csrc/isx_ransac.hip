@@ -353,15 +353,37 @@ extern "C" int isx_ransac_score(int model, const double *models_dev, int n_hyp, 
 // ------------------------------------------------------------------------------------------------
 // device: winner's inlier mask + refit + Levenberg-Marquardt, one wavefront, float64
 // ------------------------------------------------------------------------------------------------
+// Wave-wide sum / max of a double, every lane gets the result.  The value tree is that of the xor butterfly
+// (v += shfl_xor(v, m), m = 1 .. 32) -- ((v0 + v1) + (v2 + v3)) + ... -- so results are bit-identical to it, but the
+// four in-row steps are DPP moves (quad permutes, then half-row and row mirrors: after the first two steps all lanes of
+// a quad hold the same value, so any lane of the partner group will do) and the two cross-row steps read the four row
+// sums with v_readlane: no LDS crossbar round trip (~100 cycles each, twelve per reduction, and the LM step of
+// ransac_refine_kernel does 15 to 45 reductions per iteration).  Needs all 64 lanes active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-    return v;
+    v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]  (lane ^ 1)
+    v += dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]  (lane ^ 2)
+    v += dpp_f64<0x141>(v); // row_half_mirror      (a lane of the other quad of the 8-group)
+    v += dpp_f64<0x140>(v); // row_mirror           (a lane of the other 8-group of the row)
+    const double s0 = readlane_f64(v, 0), s1 = readlane_f64(v, 16), s2 = readlane_f64(v, 32), s3 = readlane_f64(v, 48);
+    return (s0 + s1) + (s2 + s3);
 }
 __device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    const double s0 = readlane_f64(v, 0), s1 = readlane_f64(v, 16), s2 = readlane_f64(v, 32), s3 = readlane_f64(v, 48);
+    return fmax(fmax(s0, s1), fmax(s2, s3));
 }
 
 // symmetric n x n eigen-decomposition in LDS by cyclic Jacobi; lanes 0..n-1 each own one index.
@@ -465,6 +487,48 @@ __device__ __forceinline__ void lm_residual(const double *h, double Mx, double M
     }
 }
 
+// solve_ge with the augmented matrix in REGISTERS: every index is a compile-time constant (loops fully unrolled, the
+// pivot row swap done as predicated element swaps), the arithmetic and its order are those of solve_ge.  One lane walking
+// an LDS-resident matrix pays ~100 cycles per dependent access, which made the LM step of ransac_refine_kernel
+// latency-bound on this routine (4.5 us per 4 x 4 solve, 25 us per 8 x 8).
+template <int N>
+__device__ __forceinline__ void solve_ge_reg(double (&Ab)[N][N + 1], double (&x)[N]) {
+#pragma unroll
+    for (int s = 0; s < N; s++) {
+        int piv = s;
+        double best = fabs(Ab[s][s]);
+#pragma unroll
+        for (int r = s + 1; r < N; r++)
+            if (fabs(Ab[r][s]) > best) { best = fabs(Ab[r][s]); piv = r; }
+#pragma unroll
+        for (int r = s + 1; r < N; r++) {
+            const bool sw = piv == r;
+#pragma unroll
+            for (int c = 0; c < N + 1; c++) {
+                const double a = Ab[s][c], b = Ab[r][c];
+                Ab[s][c] = sw ? b : a;
+                Ab[r][c] = sw ? a : b;
+            }
+        }
+        const double d = Ab[s][s];
+        if (fabs(d) < 1e-300) continue;
+#pragma unroll
+        for (int r = s + 1; r < N; r++) {
+            const double f = Ab[r][s] / d;
+#pragma unroll
+            for (int c = s; c < N + 1; c++) Ab[r][c] -= f * Ab[s][c];
+        }
+    }
+#pragma unroll
+    for (int s = N - 1; s >= 0; s--) {
+        double v = Ab[s][N];
+#pragma unroll
+        for (int c = s + 1; c < N; c++) v -= Ab[s][c] * x[c];
+        const double d = Ab[s][s];
+        x[s] = fabs(d) < 1e-300 ? 0. : v / d;
+    }
+}
+
 struct RefineShared {
     double A[81], V[81], W[9];
     double JtJ[64], Ab[72], v[8], d[8], x[8], xd[8], D[8];
@@ -552,12 +616,20 @@ __device__ __forceinline__ void lm_run(RefineShared &sh, const float2 *src, cons
     __syncthreads();
     for (int iter = 0;;) {
         if (lane == 0) {
+            double Ab[NP][NP + 1], dd[NP];
+            const double lam = sh.lambda;
+#pragma unroll
             for (int a = 0; a < NP; a++) {
-                for (int b = 0; b < NP; b++) sh.Ab[a * (NP + 1) + b] = sh.JtJ[a * NP + b] + (a == b ? sh.lambda * sh.D[a] : 0.);
-                sh.Ab[a * (NP + 1) + NP] = sh.v[a];
+#pragma unroll
+                for (int b = 0; b < NP; b++) Ab[a][b] = sh.JtJ[a * NP + b] + (a == b ? lam * sh.D[a] : 0.);
+                Ab[a][NP] = sh.v[a];
             }
-            solve_ge(sh.Ab, sh.d, NP);
-            for (int i = 0; i < NP; i++) sh.xd[i] = sh.x[i] - sh.d[i];
+            solve_ge_reg<NP>(Ab, dd);
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                sh.d[i] = dd[i];
+                sh.xd[i] = sh.x[i] - dd[i];
+            }
         }
         __syncthreads();
         const double Sd = lm_cost<NP>(sh.xd, src, dst, mask, n, lane);
@@ -612,29 +684,44 @@ __device__ __forceinline__ void lm_run(RefineShared &sh, const float2 *src, cons
     }
 }
 
-__global__ void __launch_bounds__(64) ransac_refine_kernel(int model, double *__restrict__ M, const float2 *__restrict__ src,
-                                                           const float2 *__restrict__ dst, int n, float thr2, int refit,
-                                                           int max_iters, uint8_t *__restrict__ mask,
+#define REFINE_LDS_POINTS 3072
+__global__ void __launch_bounds__(64) ransac_refine_kernel(int model, double *__restrict__ M, const float2 *src,
+                                                           const float2 *dst, int n, float thr2, int refit,
+                                                           int max_iters, uint8_t *mask,
                                                            int32_t *__restrict__ info) {
     __shared__ RefineShared sh;
+    // The points and the inlier mask are staged in LDS (up to REFINE_LDS_POINTS of them): this kernel is ONE wavefront
+    // that walks the point set about ten times (mask, normal equations and cost of every LM iteration), and from global
+    // memory each walk cost a full memory round trip with nothing else in flight -- that latency, not arithmetic, was
+    // most of its 31-35 us.  Same values, same order of operations.
+    __shared__ float2 l_src[REFINE_LDS_POINTS], l_dst[REFINE_LDS_POINTS];
+    __shared__ uint8_t l_mask[REFINE_LDS_POINTS];
     const int lane = threadIdx.x;
     const bool homog = model == MODEL_H;
     const int msz = homog ? 9 : 6;
     float F[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) F[i] = i < msz ? (float)M[i] : 0.f;
+    const bool in_lds = n <= REFINE_LDS_POINTS;
+    uint8_t *const gmask = mask;
+    if (in_lds) {
+        for (int i = lane; i < n; i += 64) l_src[i] = src[i], l_dst[i] = dst[i];
+        __syncthreads();
+        src = l_src, dst = l_dst, mask = l_mask; // (generic pointers: the helpers below read LDS through them)
+    }
     // inlier mask of the winning hypothesis (cv findInliers)
     int cnt = 0;
     for (int i = lane; i < n; i += 64) {
         const float2 s = src[i], d = dst[i];
         const int f = reproj_err_f32(homog, F, s.x, s.y, d.x, d.y) <= thr2;
         mask[i] = (uint8_t)f;
+        if (in_lds) gmask[i] = (uint8_t)f;
         cnt += f;
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) cnt += __shfl_xor(cnt, m);
     if (lane == 0) info[0] = cnt;
-    __syncthreads(); // mask[] is re-read by every lane below (global, same wave: make the stores visible)
+    __syncthreads(); // mask[] is re-read by every lane below (same wave: make the stores visible)
     __threadfence_block();
     if (cnt == 0 || max_iters < 0) return;
 
