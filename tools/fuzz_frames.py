@@ -38,6 +38,7 @@ def main(n_cases, seed0, scale=1):
         if not ref.any(): ref.flat[0] = 9
         img = content(rng, ih, iw, c)
         type_ = int(rng.integers(0, 2)); blender = int(rng.integers(0, 2))
+        classic = bool(rng.random() < 0.25)  # the <= 4.10 fixed-point warp arithmetic (Stitcher(warp_arith="classic"))
         th = np.deg2rad(rng.uniform(-12, 12)); sc = rng.uniform(0.85, 1.2)
         tx, ty = rng.uniform(-0.9 * iw, 0.9 * rw), rng.uniform(-0.9 * ih, 0.9 * rh)
         if rng.random() < 0.25: th, sc = 0.0, 1.0
@@ -47,8 +48,9 @@ def main(n_cases, seed0, scale=1):
         if type_ == 1: M = M + [[rng.uniform(-2e-4, 2e-4), rng.uniform(-2e-4, 2e-4), 1.0]]
         M = np.asarray(M, np.float64)
         tmp = tempfile.mkdtemp(prefix="isx_fuzz_")
-        st = ConsecutiveStitcher(log_level=3, output_dir=tmp, type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1, detector=object())
-        cfg = Cfg(type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1)
+        st = ConsecutiveStitcher(log_level=3, output_dir=tmp, type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1,
+                                 detector=object(), warp_arith="classic" if classic else "f32")
+        cfg = Cfg(type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1, warp_arith=1 if classic else 0)
         pts = np.zeros((5, 1, 2), np.float32)
         try:
             st.stitch_consecutive(ref)
@@ -65,7 +67,7 @@ def main(n_cases, seed0, scale=1):
             ok = False; got = repr(e)
         if not ok:
             bad += 1
-            print("MISMATCH case", seed0 + case, dict(c=c, ref=(rh, rw), img=(ih, iw), type=type_, blender=blender), "M=", M.tolist(),
+            print("MISMATCH case", seed0 + case, dict(c=c, ref=(rh, rw), img=(ih, iw), type=type_, blender=blender, classic=classic), "M=", M.tolist(),
                   None if got is None or isinstance(got, str) else (got.shape, o[0].shape), got if isinstance(got, str) else "", flush=True)
         if case % 25 == 0: print("case", case, "bad", bad, flush=True)
     print("done", n_cases, "cases,", bad, "mismatches")
