@@ -15,6 +15,8 @@ def test_fuzz_frames_against_the_oracle(cuda, orc):
     import fuzz_frames
     assert fuzz_frames.main(150, 31000) == 0
     assert fuzz_frames.main(12, 32000, 5) == 0
+    # several frames onto the same resident arena (growth, crop updates, clears); 1500 sequences ran clean
+    assert fuzz_frames.sequences(40, 33000) == 0
 
 
 def test_fuzz_frame_match_against_the_oracle(cuda, orc):

@@ -73,6 +73,64 @@ def main(n_cases, seed0, scale=1):
     print("done", n_cases, "cases,", bad, "mismatches")
     return bad
 
+def sequences(n_seq, seed0, frames_per_seq=5):
+    """Multi-frame variant: frames blended one after another onto the SAME resident arena (growth, crop updates, the
+    clears of gray == 0 leftovers), every mosaic against the oracle fed its own previous mosaic, and the arena invariant
+    (zero outside the mosaic's rectangle) after every frame."""
+    bad = 0
+    for case in range(n_seq):
+        rng = np.random.default_rng(seed0 + case)
+        c = 3 if rng.random() < 0.7 else 1
+        type_ = int(rng.integers(0, 2)); blender = int(rng.integers(0, 2))
+        tmp = tempfile.mkdtemp(prefix="isx_fuzz_")
+        st = ConsecutiveStitcher(log_level=3, output_dir=tmp, type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1,
+                                 detector=object())
+        cfg = Cfg(type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1)
+        pts = np.zeros((5, 1, 2), np.float32)
+        ref = content(rng, int(rng.integers(20, 200)), int(rng.integers(20, 260)), c)
+        if not ref.any(): ref.flat[0] = 9
+        st.stitch_consecutive(ref)
+        corners = None
+        ok, why = True, ""
+        for k in range(frames_per_seq):
+            ih, iw = int(rng.integers(8, 200)), int(rng.integers(8, 260))
+            img = content(rng, ih, iw, c)
+            rh, rw = ref.shape[:2]
+            th = np.deg2rad(rng.uniform(-8, 8)); sc = rng.uniform(0.9, 1.15)
+            tx, ty = rng.uniform(-0.7 * iw, 0.7 * rw), rng.uniform(-0.7 * ih, 0.7 * rh)
+            cs, sn = sc * np.cos(th), sc * np.sin(th)
+            M = [[cs, -sn, tx - iw / 2], [sn, cs, ty - ih / 2]]
+            if type_ == 1: M = M + [[rng.uniform(-1e-4, 1e-4), rng.uniform(-1e-4, 1e-4), 1.0]]
+            M = np.asarray(M, np.float64)
+            tf = TransformDetails(M, pts, pts)
+            try:
+                st.stitch_consecutive(img, tf)
+                o = oracle_stitch(ref, img, None, cfg, tf=(M, pts, pts), corners=corners)
+            except Exception as e:
+                ok, why = False, repr(e); break
+            if o is None or o is False:
+                break  # (the merged canvas went black: the stream resets; not followed further here)
+            got = np.asarray(st.refs[-1])
+            if not (got.shape == o[0].shape and np.array_equal(got, o[0]) and st.corners == o[1]):
+                ok, why = False, f"frame {k}: {got.shape} vs {o[0].shape}"; break
+            ar = st.refs[-1]._arena
+            outside = ar.t.clone()
+            outside[ar.y:ar.y + ar.h, ar.x:ar.x + ar.w] = 0
+            if int(outside.max()) != 0:
+                ok, why = False, f"frame {k}: arena not zero outside the mosaic"; break
+            ref, corners = o[0], o[1]
+            if ref.shape[0] * ref.shape[1] > 1500 * 1500:
+                break
+        if not ok:
+            bad += 1
+            print("MISMATCH sequence", seed0 + case, dict(c=c, type=type_, blender=blender), why, flush=True)
+    print("done", n_seq, "sequences,", bad, "mismatches")
+    return bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--sequences":
+        sys.exit(1 if sequences(int(sys.argv[2]) if len(sys.argv) > 2 else 100, int(sys.argv[3]) if len(sys.argv) > 3 else 500000) else 0)
     sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 1000,
                        int(sys.argv[3]) if len(sys.argv) > 3 else 1) else 0)
+
