@@ -12,7 +12,19 @@ static inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // status_out values of isx_frame_match
 enum { FM_OK = 0, FM_NOT_INTEGER = 1, FM_NORM_LIMIT = 2 };
-#define FM_MAX_SEG 16 // train segments of one pair (header layout below)
+#define FM_MAX_SEG 16 // train segments of one pair
+// header of the staging block (device and pinned mirror), 512 bytes:
+enum {
+    FM_H_ITEMS = 0,       // isx_knn_item[FM_MAX_SEG]
+    FM_H_OUT_START = 256, // int64[FM_MAX_SEG]
+    FM_H_COUNT = 384,     // int32[FM_MAX_SEG]: per-item good counts of the index kernel (unused by the caller)
+    FM_H_STATS = 448,     // int32[2]: isx_desc_prep's stats; read back together with ...
+    FM_H_CCOUNT = 456,    // int32: length of the compacted list
+    FM_H_BYTES = 512
+};
+static_assert(FM_MAX_SEG * 16 <= FM_H_OUT_START && FM_H_OUT_START + FM_MAX_SEG * 8 <= FM_H_COUNT &&
+                  FM_H_COUNT + FM_MAX_SEG * 4 <= FM_H_STATS && FM_H_CCOUNT + 4 <= FM_H_BYTES,
+              "isx_frame_match header layout");
 
 extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const void *t_host, int nt, int d, int dtype,
                                int norm, double ratio, int32_t *good_q_out_host, int32_t *good_t_out_host,
@@ -49,7 +61,7 @@ extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const v
     }
     // block layout (device and pinned mirror): [header 512][raw rows][-- device only below --]
     //   header: isx_knn_item[16] (256) | out_start int64[16] (128) | count int32[16] (64) | stats int32[2] | compact count int32
-    const size_t o_raw = 512, o_desc = o_raw + up256(raw_row * rows), o_cbase = o_desc + up256((size_t)d_pad * rows);
+    const size_t o_raw = FM_H_BYTES, o_desc = o_raw + up256(raw_row * rows), o_cbase = o_desc + up256((size_t)d_pad * rows);
     const size_t o_nrm = o_cbase + up256(4 * (size_t)rows), o_cin = o_nrm + up256(4 * (size_t)rows);
     const size_t o_idx = o_cin + up256(4 * (size_t)rows), o_dist = o_idx + up256(8 * (size_t)nq * n_seg);
     const size_t o_out = o_dist + up256(8 * (size_t)nq * n_seg); // read-back region: [hdr copy 64][good_q nq][good_t nq]
@@ -57,9 +69,9 @@ extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const v
     int rc = ctx_ensure_staging(ctx, total);
     if (rc != ISX_OK) return rc;
     uint8_t *H = ctx->hs_host, *D = ctx->hs_dev;
-    memset(H, 0, 512);
+    memset(H, 0, FM_H_BYTES);
     isx_knn_item *item = (isx_knn_item *)H;
-    int64_t *out_start_h = (int64_t *)(H + 256);
+    int64_t *out_start_h = (int64_t *)(H + FM_H_OUT_START);
     for (int sg = 0; sg < n_seg; sg++) {
         item[sg].q_start = 0, item[sg].nq = nq, item[sg].t_start = nq + sg * seg_rows;
         item[sg].nt = nt - sg * seg_rows < seg_rows ? nt - sg * seg_rows : seg_rows;
@@ -75,8 +87,8 @@ extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const v
     }
     ISX_HIP_TRY(hipMemcpyAsync(D, H, o_raw + raw_row * rows, hipMemcpyHostToDevice, st));
     const isx_knn_item *items_dev = (const isx_knn_item *)D;
-    const int64_t *out_start_dev = (const int64_t *)(D + 256);
-    int32_t *count_dev = (int32_t *)(D + 384), *stats_dev = (int32_t *)(D + 448), *ccount_dev = (int32_t *)(D + 456);
+    const int64_t *out_start_dev = (const int64_t *)(D + FM_H_OUT_START);
+    int32_t *count_dev = (int32_t *)(D + FM_H_COUNT), *stats_dev = (int32_t *)(D + FM_H_STATS), *ccount_dev = (int32_t *)(D + FM_H_CCOUNT);
     int32_t *idx_dev = (int32_t *)(D + o_idx);
     float *dist_dev = (float *)(D + o_dist);
     if (norm == ISX_NORM_HAMMING) {
@@ -93,7 +105,7 @@ extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const v
                                     ccount_dev, st);
     if (rc != ISX_OK) return rc;
     // one read-back: header tail (stats, compaction count) + both index lists
-    ISX_HIP_TRY(hipMemcpyAsync(D + o_out, D + 448, 64, hipMemcpyDeviceToDevice, st));
+    ISX_HIP_TRY(hipMemcpyAsync(D + o_out, D + FM_H_STATS, 64, hipMemcpyDeviceToDevice, st));
     ISX_HIP_TRY(hipMemcpyAsync(H + o_out, D + o_out, 64 + 8 * (size_t)nq, hipMemcpyDeviceToHost, st));
     ISX_HIP_TRY(hipStreamSynchronize(st));
     const int32_t *hdr = (const int32_t *)(H + o_out);
