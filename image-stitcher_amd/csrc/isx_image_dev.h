@@ -12,21 +12,26 @@ __device__ __forceinline__ int gray_px(uint32_t px) {
     return C == 3 ? gray3(px & 255, (px >> 8) & 255, (px >> 16) & 255) : (int)(px & 255);
 }
 
+// Wave-wide min / max, every lane gets the result.  Four DPP steps give every lane its 16-lane row's value (quad
+// permutes, then half-row and row mirrors: after two steps all lanes of a quad agree, so any lane of the partner group
+// will do), the four rows are combined from v_readlane: no LDS-crossbar shuffles (six dependent ones per reduction
+// before).  Every lane of the wave must be active (all call sites are in uniform control flow of full waves); `old` = v,
+// so a lane never picks up anything but a lane's own value.
 __device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const int o = __shfl_xor(v, m);
-        v = o < v ? o : v;
-    }
-    return v;
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const int o = __shfl_xor(v, m);
-        v = o > v ? o : v;
-    }
-    return v;
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -133,6 +133,15 @@ __device__ __forceinline__ bool orb_row_has_zero(const uint64_t *__restrict__ ro
 }
 
 // K3: grid (ceil(w/64), ceil(h/16)), block 256.  Writes EVERY pixel of the key map (0 = not a keypoint candidate).
+__device__ __forceinline__ int orb_wave_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false); // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false); // row_mirror: every lane holds its row's sum
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
 __global__ void __launch_bounds__(256) orb_fast_harris_kernel(const uint8_t *__restrict__ g, int h, int w, int thr, int clean,
                                                               const uint64_t *__restrict__ zb, int zw,
                                                               uint32_t *__restrict__ key) {
@@ -233,12 +242,9 @@ __global__ void __launch_bounds__(256) orb_fast_harris_kernel(const uint8_t *__r
             // ORB_E >= clean: the window lies inside the image, and inside the staged rows / words
             dirty = orb_row_has_zero(zt[ly + ORB_E - clean + lane], 3, lx + 64 - clean, lx + 64 + clean);
         }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) { // (products up to 1020^2: the three sums fit 32 bits, kept as int for the shuffles)
-            a += __shfl_xor((int)a, m);
-            b += __shfl_xor((int)b, m);
-            c += __shfl_xor((int)c, m);
-        }
+        // (products up to 1020^2: the three sums fit 32 bits.)  Row sums by four DPP steps, the four rows added on the
+        // scalar unit: no LDS-crossbar shuffles (18 of them per corner made this loop the longer half of the kernel)
+        a = orb_wave_sum((int)a), b = orb_wave_sum((int)b), c = orb_wave_sum((int)c);
         const bool any_dirty = __any(dirty);
         if (lane == 0) {
             const long long R = 25 * (a * c - b * b) - (a + c) * (a + c);
