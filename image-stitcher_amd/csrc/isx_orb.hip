@@ -133,6 +133,13 @@ __device__ __forceinline__ bool orb_row_has_zero(const uint64_t *__restrict__ ro
 }
 
 // K3: grid (ceil(w/64), ceil(h/16)), block 256.  Writes EVERY pixel of the key map (0 = not a keypoint candidate).
+__device__ __forceinline__ int orb_row_sum(int v) { // sum over each row of 16 lanes, in every lane of the row
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);
+    return v;
+}
 __device__ __forceinline__ int orb_wave_sum(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
@@ -321,11 +328,7 @@ __global__ void __launch_bounds__(64) orb_describe_kernel(const uint8_t *__restr
         }
         m01 = v * sv;
     }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        m10 += __shfl_xor(m10, m);
-        m01 += __shfl_xor(m01, m);
-    }
+    m10 = orb_wave_sum(m10), m01 = orb_wave_sum(m01);
     // orientation bin: argmax over 32 integer dot products, lowest k on ties
     long long dot = LLONG_MIN;
     int best = lane & 31;
@@ -468,10 +471,7 @@ __global__ void __launch_bounds__(256) orb_rank_kernel(const uint64_t *__restric
 #pragma unroll 8
         for (int k = 0; k < 64; k++) below += blk[16 * k + part] < mine;
     }
-    below += __shfl_xor(below, 1);
-    below += __shfl_xor(below, 2);
-    below += __shfl_xor(below, 4);
-    below += __shfl_xor(below, 8);
+    below = orb_row_sum(below); // (the 16 threads of a survivor are one DPP row)
     if (part == 0 && i < total && below < nfeatures) {
         const uint32_t idx = (uint32_t)mine;
         sel[2 + below] = (int32_t)(((idx / (uint32_t)w) << 16) | (idx % (uint32_t)w));
