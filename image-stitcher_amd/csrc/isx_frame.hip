@@ -284,8 +284,8 @@ __device__ __forceinline__ void warp_quad(const uint8_t *__restrict__ src, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1 (gradient path).  grid = qh workgroups of nw = min(nchunk, 16) waves; wave w takes the 256-pixel chunks
-// w, w+nw, ... of its row (one chunk per wave up to 4096-pixel rows).
+// K1 (gradient path).  grid = qh workgroups of nw = min(nchunk, 4) waves; wave w takes the 256-pixel chunks
+// w, w+nw, ... of its row (rotated by the row, see below).
 // ------------------------------------------------------------------------------------------------
 #ifndef ISX_K1_WAVES
 #define ISX_K1_WAVES 6
@@ -876,9 +876,14 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
     }
     ISX_REQUIRE(src_dev && mosaic_q_dev && mpitch >= (int64_t)q_w * c, "null device pointer / bad mosaic pitch");
     const int nchunk = (q_w + 255) / 256;
-    // waves per row workgroup: a wave per 256-pixel chunk for the warp kernel; the fused alpha kernel (120 VGPRs, 4 waves
-    // per SIMD) measured 1 us faster with four waves that take two chunks each at 1080p
-    const int max_waves = blender == ISX_BLEND_GRADIENT ? FRAME_MAX_WAVES : 4;
+    // waves per row workgroup: FOUR, each taking every fourth 256-pixel chunk of the row (two chunks at 1080p).  All row
+    // workgroups of a 1080p frame are then resident at once (1190 x 4 waves on 1024 SIMDs at 5-6 waves each) instead of
+    // running as two generations that each wait for their first loads: the fused alpha kernel measured 1 us faster than
+    // with a wave per chunk, the warp kernel 0.5 us (11.8 -> 11.3; two waves per row: 13.1)
+#ifndef ISX_K1_MAX_WAVES
+#define ISX_K1_MAX_WAVES 4
+#endif
+    const int max_waves = blender == ISX_BLEND_GRADIENT ? ISX_K1_MAX_WAVES : 4;
     const int row_threads = 64 * (nchunk < max_waves ? nchunk : max_waves);
     const int row_blocks = 8 * ((q_h + 7) / 8); // frame_row_of_block()
     const bool persp = model == ISX_MODEL_HOMOGRAPHY, classic = arith == ISX_WARP_CLASSIC;
