@@ -272,6 +272,17 @@ __device__ __forceinline__ int frame_row_of_block(int qh) {
     return (int)(blockIdx.x & 7) * rpx + (int)(blockIdx.x >> 3);
 }
 
+// Ballot of "gray != 0" over the wave.  BGR: gray != 0 whenever G != 0 (19235 >= 16384, gray3); the exact test only runs
+// if some pixel of the wave is non-zero with G == 0.
+template <int C>
+__device__ __forceinline__ uint64_t ballot_gray_nz(uint32_t p) {
+    if (C == 3) {
+        const uint64_t g = __ballot((p & 0xFF00u) != 0u), nz = __ballot(p != 0u);
+        return (nz & ~g) ? __ballot(gray_px<C>(p) != 0) : g;
+    }
+    return __ballot((p & 255u) != 0u);
+}
+
 template <int C, bool PERSP, bool CLASSIC>
 __device__ __forceinline__ void warp_quad(const uint8_t *__restrict__ src, const WarpParams &P, int X0, int Y, int n_valid,
                                           uint32_t (&px)[4]) {
@@ -325,14 +336,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ISX_K
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             bc[i] = __ballot((px[i] & 255u) != 0u);
-            if (C == 3) {
-                // gray != 0 whenever G != 0 (19235 >= 16384, gray3); the exact test only runs if some pixel of the wave
-                // is non-zero with G == 0
-                const uint64_t g = __ballot((px[i] & 0xFF00u) != 0u), nz = __ballot(px[i] != 0u);
-                bg[i] = (nz & ~g) ? __ballot(gray_px<C>(px[i]) != 0) : g;
-            } else {
-                bg[i] = bc[i];
-            }
+            bg[i] = C == 3 ? ballot_gray_nz<C>(px[i]) : bc[i];
         }
         const int cx = P.dx0 + chunk * 256;
 #pragma unroll
@@ -760,15 +764,29 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
 // alpha path: warp + seamless_merge in place over all of Q (outside Q the warped image is 0 and the merged
 // canvas equals the mosaic).  Per-row table (6 ints): warped gray extent, merged gray extent, zeroed, dirty.
 // ------------------------------------------------------------------------------------------------
+// (5 waves per SIMD = 96 VGPRs: the 1190 four-wave row workgroups of a 1080p frame are then all resident at once; at the
+// 104 VGPRs the compiler takes by itself a fifth of them waits for a slot and runs as a second generation: 15.2 -> 13.7 us)
+#ifndef ISX_KA_WAVES
+#define ISX_KA_WAVES 5
+#endif
 template <int C, bool PERSP, bool CLASSIC>
-__global__ void __launch_bounds__(1024) frame_warp_alpha_kernel(const uint8_t *__restrict__ src, const WarpParams P,
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ISX_KA_WAVES))) frame_warp_alpha_kernel(const uint8_t *__restrict__ src, const WarpParams P,
                                                                uint8_t *mosaic_q, int64_t mpitch, int nchunk,
                                                                double contrib, double one_minus, int clip_y0, int clip_y1,
                                                                int32_t *__restrict__ rows) {
     const int ly = frame_row_of_block(P.dh);
     if (ly >= P.dh) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int gl = INT_MAX, gr = -1, ml = INT_MAX, mr = -1, zeroed = 0, dirty = 0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    // trunc(c * ref) and trunc((1 - c) * warped) of proc.py:70-71 for every byte value, the float64 products formed once per
+    // workgroup: in the overlap a channel costs two LDS byte reads (256-byte tables: one dword per bank, no conflicts)
+    // instead of two int -> double conversions, two float64 products and two conversions back
+    __shared__ uint8_t tab_ref[256], tab_warped[256];
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+        tab_ref[t] = (uint8_t)(int)(contrib * (double)t);
+        tab_warped[t] = (uint8_t)(int)(one_minus * (double)t);
+    }
+    __syncthreads();
+    int gl = INT_MAX, gr = -1, ml = INT_MAX, mr = -1, zeroed = 0, dirty = 0; // (wave-uniform: found from ballots)
     uint8_t *mrow = mosaic_q + (int64_t)ly * mpitch;
     // rows of another strip of the mosaic (another GPU): the warped row still counts for bbox(warped), the mosaic is
     // neither read nor written
@@ -776,32 +794,53 @@ __global__ void __launch_bounds__(1024) frame_warp_alpha_kernel(const uint8_t *_
     for (int chunk = wave; chunk < nchunk; chunk += nw) {
         const int lx = chunk * 256 + 4 * lane;
         const int nv = min(4, max(0, P.dw - lx));
+        // (pixels at or beyond the end of the row: the warp yields 0 for them, the mosaic reads as 0, so they blend to 0
+        // and take no part in any extent or flag below)
         uint32_t px[4], pb[4] = {0u, 0u, 0u, 0u}, po[4];
         if (nv > 0 && mine) quad_load<C>(mrow, lx, P.dw, pb);
         warp_quad<C, PERSP, CLASSIC>(src, P, P.dx0 + lx, P.dy0 + ly, nv, px);
+        if (!__any((pb[0] | pb[1] | pb[2] | pb[3]) != 0u)) {
+            // nothing of the mosaic under this wave: warped + 0
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            po[i] = alpha_px<C>(px[i], pb[i], contrib, one_minus);
-            const int X = P.dx0 + lx + i;
-            if (i >= nv) continue;
-            if (gray_px<C>(px[i]) != 0) {
-                gl = min(gl, X);
-                gr = max(gr, X);
-            }
-            if (!mine) continue;
-            if (gray_px<C>(po[i]) != 0) {
-                ml = min(ml, X);
-                mr = max(mr, X);
-            } else {
-                if (po[i] != 0u) dirty = 1;
-                if (gray_px<C>(pb[i]) != 0) zeroed = 1;
+            for (int i = 0; i < 4; i++) po[i] = px[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // outside the overlap: uint8 + uint8 with wrap-around (proc.py:79), all channels at once (carries between
+                // the bytes suppressed)
+                po[i] = ((px[i] & 0x7F7F7Fu) + (pb[i] & 0x7F7F7Fu)) ^ ((px[i] ^ pb[i]) & 0x808080u);
+                if (gray_px<C>(px[i]) > 10 && gray_px<C>(pb[i]) > 10) { // overlap = mask1 & mask2 (proc.py:58-66)
+                    uint32_t o = 0;
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        o |= (((uint32_t)tab_warped[(px[i] >> (8 * c)) & 255u] + (uint32_t)tab_ref[(pb[i] >> (8 * c)) & 255u]) & 255u) << (8 * c);
+                    po[i] = o;
+                }
             }
         }
         if (nv > 0 && mine) quad_store<C>(mrow, lx, P.dw, po);
+        // extents and flags from ballots (bit l of word i = pixel 4*l + i of the chunk), on the scalar unit
+        const int cx = P.dx0 + chunk * 256;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint64_t gw = ballot_gray_nz<C>(px[i]);
+            if (gw) {
+                gl = min(gl, cx + 4 * (int)__builtin_ctzll(gw) + i);
+                gr = max(gr, cx + 4 * (63 - (int)__builtin_clzll(gw)) + i);
+            }
+            if (!mine) continue;
+            const uint64_t go = ballot_gray_nz<C>(po[i]);
+            if (go) {
+                ml = min(ml, cx + 4 * (int)__builtin_ctzll(go) + i);
+                mr = max(mr, cx + 4 * (63 - (int)__builtin_clzll(go)) + i);
+            }
+            if (~go) { // some pixel is written with gray == 0: was it gray != 0 before (zeroed), is a byte of it != 0 (dirty)
+                if (C == 3 && (__ballot(po[i] != 0u) & ~go)) dirty = 1; // (C = 1: gray == 0 means the byte is 0)
+                if (ballot_gray_nz<C>(pb[i]) & ~go) zeroed = 1;
+            }
+        }
     }
     __shared__ int red[FRAME_MAX_WAVES][6];
-    gl = wave_min(gl), gr = wave_max(gr), ml = wave_min(ml), mr = wave_max(mr);
-    zeroed = wave_max(zeroed), dirty = wave_max(dirty);
     if (lane == 0)
         red[wave][0] = gl, red[wave][1] = gr, red[wave][2] = ml, red[wave][3] = mr, red[wave][4] = zeroed,
         red[wave][5] = dirty;
