@@ -610,18 +610,19 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
     // (another GPU) and are never read or written here: [gy0, gy1) is what this call blends
     const int gx0 = res[R_ROI + 0], ry0 = res[R_ROI + 1], gx1 = res[R_ROI + 2], ry1 = res[R_ROI + 3];
     const int gy0 = max(ry0, clip_y0), gy1 = min(ry1, clip_y1);
-    // alpha = k / feather for k = 0 .. feather (proc.py:220, :225, :239, :244), divided once per workgroup:
-    // the same IEEE quotient as the reference's per-pixel division
-    __shared__ double ftab[64];
+    // alpha = k / feather for k = 0 .. feather (proc.py:220, :225, :239, :244): the same IEEE quotient as the reference's
+    // per-pixel division, formed ONCE PER WAVE THAT MEETS A FEATHER BAND into that wave's own table (no workgroup barrier:
+    // the nine waves in ten that never read it pay neither the float64 division nor the wait for it)
+    __shared__ double ftab_w[4][64];
     __shared__ int red[4][6];
-    if (threadIdx.x <= feather) ftab[threadIdx.x] = (double)(int)threadIdx.x / (double)feather;
+    double *ftab = ftab_w[wave];
+    bool have_ftab = false; // wave-uniform
     if (threadIdx.x == 0) mypart[0] = mypart[1] = INT_MAX, mypart[2] = mypart[3] = -1, mypart[4] = mypart[5] = 0;
     if (!found || !rows_ok) return;
     // workgroup entirely outside the ROI (block-uniform)
     if (qx0 + bx * 256 >= gx1 || qx0 + bx * 256 + 256 <= gx0 || qy0 + lyb >= gy1 ||
         qy0 + lyb + 4 * G3_IT <= gy0)
         return;
-    __syncthreads();
     const int T4[4] = {T.x, T.y, T.z, T.w}, B4[4] = {B.x, B.y, B.z, B.w};
     const bool cols_all = Xw >= gx0 && Xw + 64 <= gx1 && lxw + 64 <= qw;     // wave-uniform
     const bool wave_out = Xw >= gx1 || Xw + 64 <= gx0 || lxw >= qw;         // wave-uniform
@@ -685,6 +686,13 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
         continue;
 #endif
         any_general = true;
+        if (slow && !have_ftab) { // (feather < 64: one lane per entry; LDS accesses of a wave complete in order)
+            if (lane <= feather) ftab[lane] = (double)lane / (double)feather;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            have_ftab = true;
+        }
         const bool row_in = ly < qh && Y >= gy0 && Y < gy1;
         uint32_t pw[4], pr[4], po[4];
         raw_unpack<C>(dw[it], pw);
