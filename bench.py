@@ -313,6 +313,7 @@ def main():
         allc = prs.gather_counts(c.view(-1, 2), len(all_pairs), rank, world)
         if record:
             marks[3].record()
+            torch.cuda.synchronize()  # (instrumented steps only: the host figure below must not include the wait for the GPU)
         t_host = time.perf_counter()
         if rank == 0:
             h = allc.cpu().numpy()
