@@ -47,10 +47,12 @@ def main(n_cases, seed0, scale=1):
         M = [[cs, -sn, tx - iw / 2], [sn, cs, ty - ih / 2]]
         if type_ == 1: M = M + [[rng.uniform(-2e-4, 2e-4), rng.uniform(-2e-4, 2e-4), 1.0]]
         M = np.asarray(M, np.float64)
+        # (drawn last, so a seed keeps its geometry; 0.5 alone would never round in the overlap's products)
+        contrib = float(rng.choice([0.5, 0.2, 0.73, 1.0 / 3.0, 0.0, 1.0, 0.999]))
         tmp = tempfile.mkdtemp(prefix="isx_fuzz_")
-        st = ConsecutiveStitcher(log_level=3, output_dir=tmp, type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1,
+        st = ConsecutiveStitcher(log_level=3, output_dir=tmp, type=type_, blender=blender, ref_image_contrib=contrib, consecutive_range=1,
                                  detector=object(), warp_arith="classic" if classic else "f32")
-        cfg = Cfg(type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1, warp_arith=1 if classic else 0)
+        cfg = Cfg(type=type_, blender=blender, ref_image_contrib=contrib, consecutive_range=1, warp_arith=1 if classic else 0)
         pts = np.zeros((5, 1, 2), np.float32)
         try:
             st.stitch_consecutive(ref)
@@ -83,9 +85,10 @@ def sequences(n_seq, seed0, frames_per_seq=5):
         c = 3 if rng.random() < 0.7 else 1
         type_ = int(rng.integers(0, 2)); blender = int(rng.integers(0, 2))
         tmp = tempfile.mkdtemp(prefix="isx_fuzz_")
-        st = ConsecutiveStitcher(log_level=3, output_dir=tmp, type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1,
+        contrib = [0.5, 0.2, 0.73, 1.0 / 3.0][case % 4]
+        st = ConsecutiveStitcher(log_level=3, output_dir=tmp, type=type_, blender=blender, ref_image_contrib=contrib, consecutive_range=1,
                                  detector=object())
-        cfg = Cfg(type=type_, blender=blender, ref_image_contrib=0.5, consecutive_range=1)
+        cfg = Cfg(type=type_, blender=blender, ref_image_contrib=contrib, consecutive_range=1)
         pts = np.zeros((5, 1, 2), np.float32)
         ref = content(rng, int(rng.integers(20, 200)), int(rng.integers(20, 260)), c)
         if not ref.any(): ref.flat[0] = 9
