@@ -46,7 +46,8 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #endif
 #ifndef ISX_KNN_DIAG
 #define ISX_KNN_DIAG 0 /* timing diagnostics, compile time only (tools/build_diag.sh); results are WRONG when != 0:
-                          1 no global loads, 4 no barriers, 8 no fold */
+                          1 no global loads, 4 no barriers, 8 no fold, 16 no exact rescan of ambiguous queries
+                          (knn2_count16w_kernel; needed with 1 / 4, whose garbage tiles make most queries ambiguous) */
 #endif
 #define ISX_BIAS 6291456 /* 3 << 21 : keeps val = 2dot - nb' + BIAS in [32768, 2^23] */
 
@@ -1192,7 +1193,7 @@ knn2_count16w_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict_
                 amb = (g_best != g_worst) || (flags & 1);
             }
         }
-        unsigned long long am = __ballot(amb);
+        unsigned long long am = (ISX_KNN_DIAG & 16) ? 0ull : __ballot(amb);
         while (am) {
             const int L = __ffsll((long long)am) - 1;
             am &= am - 1;
