@@ -235,25 +235,31 @@ def stitch_workload(dev, n_frames):
     }
 
 
-def cpu_baseline(des, pairs, ratio, seconds):
+def cpu_baseline(des, pairs, ratio, seconds, gpu_counts=None):
     """Oracle port of the reference's per-pair CPU work (float32 descriptors as cv2.SIFT returns them:
-    BFMatcher L2 + Python ratio loop), multi-threaded over query rows like cv2's parallel_for_."""
+    BFMatcher L2 + Python ratio loop), multi-threaded over query rows like cv2's parallel_for_.  The oracle's
+    counts of the sampled pairs are compared with the GPU's counts of the same pairs (gpu_counts[p] = both
+    directions of pairs[p], from the last step): "sample_counts_equal"."""
     from oracle import orc
     threads = max(1, min(16, os.cpu_count() or 1))
     rng = np.random.default_rng(0)
-    sample = pairs[rng.permutation(len(pairs))]
-    done = 0
+    order = rng.permutation(len(pairs))
+    done, equal = 0, True
     t0 = time.perf_counter()
-    for (i, j) in sample:
+    for p in order:
+        i, j = pairs[p]
         a = des[i].astype(np.float32)
         b = des[j].astype(np.float32)
-        orc.match_count(a, b, ratio, nthreads=threads)
-        orc.match_count(b, a, ratio, nthreads=threads)
+        cij = orc.match_count(a, b, ratio, nthreads=threads)
+        cji = orc.match_count(b, a, ratio, nthreads=threads)
+        if gpu_counts is not None:
+            equal = equal and (cij, cji) == (int(gpu_counts[p, 0]), int(gpu_counts[p, 1]))
         done += 1
         if time.perf_counter() - t0 > seconds and done >= 2:
             break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "image pairs matched/s", "cores": threads, "kind": "port",
+            "sample_counts_equal": bool(equal) if gpu_counts is not None else None,
             "sample": f"{done} unordered pairs (both directed knnMatch float32 4096x4096x128 + ratio loops) "
                       f"drawn at random from the same 512-image set, {dt:.1f} s, oracle/orc_match.c with OpenMP"}
 
@@ -318,7 +324,7 @@ def main():
         if rank == 0:
             h = allc.cpu().numpy()
             comps, _ = prs.components_from_counts(n, all_pairs, h[:, 0], h[:, 1], min_match)
-            result["comps"] = comps
+            result["comps"], result["counts"] = comps, h
         if record:
             torch.cuda.synchronize()
             host_ms = (time.perf_counter() - t_host) * 1e3
@@ -400,7 +406,7 @@ def main():
         }
         line["step_breakdown"] = breakdown
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(des, all_pairs, ratio, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(des, all_pairs, ratio, args.cpu_seconds, gpu_counts=result["counts"])
         if world == 1 and not args.no_stitch:
             del des, local
             line["stitch"] = stitch_workload(dev, args.stitch_frames)

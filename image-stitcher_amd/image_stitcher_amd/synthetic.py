@@ -40,6 +40,38 @@ def overlapping_crops_descriptors(seed=1234, n_scenes=8, imgs_per_scene=64, kp=4
     return des, scene_of
 
 
+def overlapping_crops_descriptors_device(device, seed=77, n_scenes=64, imgs_per_scene=64, kp=4096, step=448, d=128,
+                                         noise_sigma=6.0):
+    """The same construction as overlapping_crops_descriptors, generated ON THE DEVICE with torch's generator (BASELINE
+    configs[4] is 4096 images x 4096 kp = 2 GiB of descriptors: minutes of numpy on the host, under a second here).
+    The values differ from the numpy generator's (another random stream); whoever needs an image on the host
+    downloads it.  Returns (des uint8 tensor (n, kp, d) on `device`, scene_of int64 ndarray (n,))."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    pool_n = (imgs_per_scene - 1) * step + kp
+    n = n_scenes * imgs_per_scene
+    des = torch.empty((n, kp, d), dtype=torch.uint8, device=device)
+    order = torch.randperm(n, generator=g, device=device).cpu().numpy()   # global image shuffle: slot -> (scene, k)
+    scene_of = np.empty((n,), np.int64)
+    slot_of = np.empty((n,), np.int64)
+    slot_of[order] = np.arange(n)
+    for s in range(n_scenes):
+        x = torch.empty((pool_n, d), dtype=torch.float32, device=device).exponential_(1.0, generator=g)
+        x /= x.norm(dim=1, keepdim=True)
+        x.clamp_(max=0.2)
+        x /= x.norm(dim=1, keepdim=True)
+        pool = torch.clamp(torch.round(x * 512.0), 0, 255)
+        for k in range(imgs_per_scene):
+            base = pool[k * step:k * step + kp]
+            noise = torch.round(torch.randn(base.shape, generator=g, device=device) * noise_sigma)
+            img = torch.clamp(base + noise, 0, 255).to(torch.uint8)
+            slot = int(slot_of[s * imgs_per_scene + k])
+            des[slot] = img[torch.randperm(kp, generator=g, device=device)]
+            scene_of[slot] = s
+    return des, scene_of
+
+
 def orb_like_descriptors(seed=1235, n_images=8, kp=500, d=32, flips=8, overlap=0.5):
     """Uniform random byte descriptors; consecutive images share `overlap` of their rows up to
     `flips` random bit flips (planted neighbours)."""

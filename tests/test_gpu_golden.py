@@ -87,9 +87,35 @@ def test_golden_image_chain(cuda, gold, c):
     assert np.array_equal(roi.cpu().numpy(), gold[f"grad{c}"])
 
 
-def test_full_size_all_pairs_properties(cuda):
+def oracle_sample_of_directed_items(c, all_pairs, n_items, min_match, rng):
+    """Indices (pair, direction) into the count matrix c[pairs, 2] to recount with the oracle: a third with counts
+    >= min_match (the union edges), a third drawn at random (almost all unrelated images), and every item -- up to a
+    third -- whose count lies within +-2 of min_match (the ones whose rounding decides an edge)."""
+    flat = c.reshape(-1)
+    near = np.nonzero(np.abs(flat - min_match) <= 2)[0]
+    big = np.nonzero(flat >= min_match)[0]
+    k = n_items // 3
+    pick = [rng.choice(near, min(k, len(near)), replace=False)] if len(near) else []
+    pick.append(rng.choice(big, min(k, len(big)), replace=False))
+    pick.append(rng.choice(len(flat), n_items - sum(len(p) for p in pick), replace=False))
+    pick = np.unique(np.concatenate(pick))
+    return [(int(f // 2), int(f % 2)) for f in pick], len(near)
+
+
+def assert_counts_match_oracle(orc, des_of, c, all_pairs, sample, ratio, nthreads=8):
+    """c[p, 0] = good matches of (query all_pairs[p,0], train all_pairs[p,1]), c[p, 1] the other direction
+    (reference stitcher.py:292-296); des_of(i) returns image i's descriptors as the uint8 rows cv2 would hold as float32."""
+    for p, d in sample:
+        i, j = (int(v) for v in all_pairs[p])
+        q, t = (i, j) if d == 0 else (j, i)
+        want = orc.match_count(des_of(q).astype(np.float32), des_of(t).astype(np.float32), ratio, nthreads=nthreads)
+        assert int(c[p, d]) == want, f"directed item ({q}->{t}): GPU {int(c[p, d])}, oracle {want}"
+
+
+def test_full_size_all_pairs_properties(cuda, orc):
     """BASELINE.json configs[2] at full size (512 x 4096 x 128, 261,632 directed items per launch).  The
-    oracle would need hours here, so the count matrix is checked through properties that hold at any size:
+    oracle would need hours for all of it, so 48 directed items of this very launch are recounted with the oracle
+    (knnMatch float32 + ratio loop, stitcher.py:292-293) and the whole matrix is checked through properties that hold at any size:
       (a) relabelling invariance: shuffling the image order and the row order inside every image permutes
           the count matrix and changes nothing else (ties between equal distances could move a match between
           two equal rows but never change a count);
@@ -113,6 +139,10 @@ def test_full_size_all_pairs_properties(cuda):
         torch.cuda.synchronize()
         return c.cpu().numpy()
     c0 = run(des, items).reshape(-1, 2)
+    # oracle sample of THIS launch
+    sample, n_near = oracle_sample_of_directed_items(c0, all_pairs, 48, 5, np.random.default_rng(11))
+    assert len(sample) >= 40
+    assert_counts_match_oracle(orc, lambda i: des[i], c0, all_pairs, sample, 0.65)
     # (c)
     comps, _ = prs.components_from_counts(n, all_pairs, c0[:, 0], c0[:, 1], 5)
     truth = sorted(sorted(np.nonzero(scene_of == s)[0].tolist()) for s in range(8))

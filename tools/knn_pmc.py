@@ -20,7 +20,7 @@ plan = ops.plan_items(items, src.device, train_group=tg)
 for rep in range(reps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     if mode == "count":
-        c = ops.knn2_l2_items(P, None, 0.65, plan=plan)
+        c = ops.knn2_l2_items(P, None, 0.65, plan=plan, verify_all=int(os.environ.get('ISX_COUNT_FLAGS', '0')))  # flags: 0 = count16w, 4 = count16, 2 = 32x32x32
     else:
         c, _ = ops.knn2_l2_items(P, None, 0.65, plan=plan, want_matches=True)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
