@@ -19,6 +19,7 @@
 // ISX_L2_EXACT_LIMIT, so integer ranking == cv2's float ranking (checked by the caller).
 #include "isx_common.h"
 #include <float.h>
+#include <type_traits>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -490,6 +491,56 @@ __device__ __noinline__ void knn2_exact_scan(const int8_t *__restrict__ desc, co
             v1 = v;
         } else if (v > v2) {
             v2 = v;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const int o1 = __shfl_xor(v1, m), o2 = __shfl_xor(v2, m);
+        const int hi = v1 > o1 ? v1 : o1, lo = v1 > o1 ? o1 : v1;
+        const int s = v2 > o2 ? v2 : o2;
+        v1 = hi;
+        v2 = lo > s ? lo : s;
+    }
+}
+
+// The same for 128-byte rows with coalesced loads: 8 lanes share a train row (16 bytes each), so one dwordx4 instruction
+// reads 8 whole rows (1 KB contiguous) and 16 of them are in flight per step.  The scan above walks one row per lane
+// (64 cache lines per load instruction, 8 loads in flight) and is bound by memory latency: ~350 us per 4096 rows against
+// ~25 us here, which matters where many queries are recounted (knn2_pair_filter_kernel).
+__device__ __noinline__ void knn2_exact_scan128(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm,
+                                                int q_row, int t_start, int nt, int lane, int &v1, int &v2) {
+    constexpr int UNR = 16;
+    const int slot = lane & 7, sub = lane >> 3;
+    const v4i q = *(const v4i *)(desc + (int64_t)q_row * 128 + slot * 16);
+    v1 = INT32_MIN;
+    v2 = INT32_MIN;
+    for (int j0 = 0; j0 < nt; j0 += 8 * UNR) {
+        v4i x[UNR];
+        int nb[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int row = j0 + u * 8 + sub;
+            x[u] = row < nt ? *(const v4i *)(desc + (int64_t)(t_start + row) * 128 + slot * 16) : v4i{0, 0, 0, 0};
+            nb[u] = (row < nt && slot == 0) ? nrm[t_start + row] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            int dot = __builtin_amdgcn_sdot4(q[0], x[u][0], 0, false);
+            dot = __builtin_amdgcn_sdot4(q[1], x[u][1], dot, false);
+            dot = __builtin_amdgcn_sdot4(q[2], x[u][2], dot, false);
+            dot = __builtin_amdgcn_sdot4(q[3], x[u][3], dot, false);
+            dot += __shfl_xor(dot, 1);
+            dot += __shfl_xor(dot, 2);
+            dot += __shfl_xor(dot, 4);
+            if (slot == 0 && j0 + u * 8 + sub < nt) { // one lane per row keeps it: the merge below must see every row once
+                const int v = 2 * dot - nb[u];
+                if (v > v1) {
+                    v2 = v1;
+                    v1 = v;
+                } else if (v > v2) {
+                    v2 = v;
+                }
+            }
         }
     }
 #pragma unroll
@@ -1242,6 +1293,381 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
             hipLaunchKernelGGL((knn2_count_kernel<1>), grid, block, 0, st, desc_dev, nrm_dev, cin_dev, it, n, nqb, ratio, co, flags);
     }
     return isx_launch_status("knn2_count_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// knn2_pair_filter_kernel (round 3): BOTH directions of an unordered image pair from ONE distance matrix -- half the
+// matrix instructions of the two-pass count kernels above.  reference stitcher.py:285-296 visits (i, j) and (j, i);
+// both need the same 4096 x 4096 products.
+//
+// What made "both directions from one tile" lose in round 2 (profiles/r02_bidir_probe.md) was the vector work of two
+// EXACT top-2 folds (3.5 three-input ops per value).  This kernel does not rank exactly.  It keeps, per direction, only
+// MAXIMA OF GROUPS of candidates (0.5 op per value and direction) and proves from them that a query is certainly NOT a
+// good match, which is what almost every query of almost every pair of get_collections is:
+//     H1      = the largest group maximum          = the query's best value, exactly
+//     H2lo    = the second largest group maximum  <= its true second best value (two distinct candidates reach it)
+//     good needs d1 < ratio * d2; with d2 <= d(H2lo) the test can only get harder, so "not good at (d(H1), d(H2lo))"
+//     is final.  Whoever passes is a CANDIDATE: up to ISX_PAIR_CAP per direction are recounted exactly by a wave
+//     (knn2_exact_scan); a direction with more (overlapping images) is reported as -1 and the caller runs it on the
+//     two-pass kernel.  Counts are therefore the exact counts, bit for bit, whatever the filter lets through.
+// Column direction (query = item.q image, train = item.t image): as in knn2_count16w_kernel the train norm rides in the
+// MFMA's C input, a lane owns 8 x 16 queries, two max-only streams per column block.  Row direction (query = a row of
+// item.t, candidates = the rows of item.q): the value that ranks along a row is raw - n_q/2; instead of one subtraction
+// per value the element-wise maximum over the wave's 8 column blocks (128 queries = one CLASS) is corrected ONCE by the
+// class's smallest half norm (an upper bound) and tagged with the class, reduced 16 -> 4 lanes (2 DPP steps) and
+// folded into a per-row table in LDS with ds_max_u32; the class's norm spread is taken off again where a LOWER bound is
+// needed.  Rows sorted by norm inside an image (ops.prepare_descriptor_tensor(sort_rows=True); counts do not depend on the
+// row order) make that spread small; unsorted input is still exact, only more candidates pass.
+// One workgroup (8 waves, 2 per SIMD) per pair, the query image in 4 passes of 1024; the train image streams through the
+// three LDS-DMA buffers once per pass.
+// ------------------------------------------------------------------------------------------------
+#define ISX_PAIR_CAP 128
+#define ISX_PAIR_SPREAD 16384 /* norm spread of a class (128 query rows) beyond which it takes the per-value correction */
+#ifndef ISX_PAIR_T
+#define ISX_PAIR_T 0 /* compile-time timing diagnostics (tools/build_variant.sh), results WRONG when != 0: 1 no row-direction fold,
+                        2 no column fold, 4 no exact recounts, 8 row fold without its LDS atomics, 16 report the candidate counts,
+                        32 exactly 16 recounts per direction */
+#endif
+#define ISX_PAIR_MAX_ROWS 4096
+#define ISX_B3 (1 << 22) /* bias of the packed row-direction bound: keeps it positive */
+#define ISX_PAIR_LDS (3 * (128 * 128 + 128 * 4) + 256 + ISX_PAIR_MAX_ROWS * 16 + 64 * 4 + (4 + 2 * ISX_PAIR_CAP) * 4)
+
+__device__ __forceinline__ unsigned dpp_quad_max(unsigned v) { // maximum over each group of 4 lanes, in every lane
+    unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); // quad_perm [1,0,3,2]
+    v = v > o ? v : o;
+    o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);          // quad_perm [2,3,0,1]
+    return v > o ? v : o;
+}
+
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm, const int32_t *__restrict__ cin,
+                        const isx_knn_item *__restrict__ items, int n_items, double ratio,
+                        int32_t *__restrict__ count_out, int flags) {
+    constexpr int DP = 128, SLOTS = 8, SH = 1, CHUNK = 128, NCB = 8;
+    constexpr int BUF = CHUNK * DP + CHUNK * 4;
+    constexpr int QPW = 16 * NCB, QPB = WAVES * QPW;
+    extern __shared__ __align__(16) unsigned char smem[];
+    // (one dummy tile in front: the software pipeline's first fold runs on an all-zero accumulator of "tile -1")
+    unsigned *rowtab = (unsigned *)(smem + 3 * BUF + 256);           // [ISX_PAIR_MAX_ROWS][4]: packed (bound << 5 | class)
+    int *cls = (int *)(smem + 3 * BUF + 256 + ISX_PAIR_MAX_ROWS * 16);     // [32][2]: bound offset, 2 floor(nmin/2) - nmax
+    int *lst = cls + 64;                                             // n_col, n_row, good_col, good_row, col list, row list
+
+    const int item_i = blockIdx.x;
+    if (item_i >= n_items) return;
+    const isx_knn_item it = items[item_i];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, col = lane & 15;
+    const int nt = it.nt, nq = it.nq;
+    const int n_chunks = (nt + CHUNK - 1) / CHUNK;
+    const int n_pass = (nq + QPB - 1) / QPB;
+
+    for (int i = tid; i < n_chunks * CHUNK; i += 64 * WAVES) ((uint4 *)rowtab)[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < 4) lst[tid] = 0;
+
+    const __amdgpu_buffer_rsrc_t rs_desc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(desc + (int64_t)it.t_start * DP), 0, nt * DP, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cin =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(cin + it.t_start), 0, nt * 4, 0x00020000);
+    constexpr int ROWS_PP = 1024 / DP;
+    constexpr int PIECES = CHUNK * DP / 1024;
+    constexpr int PPW = (PIECES + WAVES - 1) / WAVES;
+    const int r_in = lane / SLOTS;
+    const int lane_voff = r_in * DP + (((lane % SLOTS) ^ (((wave * ROWS_PP + r_in) >> SH) & (SLOTS - 1))) << 4);
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    const unsigned smem_lds = (unsigned)(size_t)smem;
+    auto stage_chunk = [&](int c, int bufi) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int k = 0; k < PPW; k++) {
+            const int piece = wv + WAVES * k;
+            if (PIECES % WAVES != 0 && piece >= PIECES) break;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_desc, (lds_ptr_t)(smem_lds + bufi * BUF + piece * 1024), 16, lane_voff,
+                                                     c * (CHUNK * DP) + piece * 1024, 0, 0);
+        }
+        if (wv < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cin, (lds_ptr_t)(smem_lds + bufi * BUF + CHUNK * DP + wv * 256), 4,
+                                                     lane * 4, c * (CHUNK * 4) + wv * 256, 0, 0);
+    };
+#pragma clang diagnostic pop
+    struct Frag {
+        v4i a[2];
+        v4i cv;
+    };
+    auto read_frag = [&](const unsigned char *base, int t, Frag &f) {
+        const int row = t * 16 + col;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int slot = 4 * ks + g;
+            f.a[ks] = *(const v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4));
+        }
+        f.cv = *(const v4i *)(base + CHUNK * DP + (t * 16 + 4 * g) * 4);
+    };
+    // this lane's slot of the row table for register 0 of tile 0 of chunk 0 (quad leaders write): row 4g, group (lane>>2)&3
+    // as an LDS byte address, one tile back (the dummy tile): the fold adds (tile + 1) * 256 + 16 r as an immediate
+    const unsigned row_slot_lds = smem_lds + 3 * BUF + ((4 * g) * 4 + ((lane >> 2) & 3)) * 4;
+
+    for (int pass = 0; pass < n_pass; pass++) {
+        const int q0 = pass * QPB + wave * QPW;
+        const bool wave_live = q0 < nq;
+        const bool ragged = q0 + QPW > nq;
+        bool slow = ragged; // this class folds the row direction with one correction per VALUE (below)
+        const int cls_id = pass * WAVES + wave;
+        v4i qf[NCB][2];
+        unsigned phantom = 0; // bit cb: this lane's column of block cb is beyond nq
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            const int qi = q0 + cb * 16 + col;
+            const v4i *p = (const v4i *)(desc + (int64_t)(it.q_start + (qi < nq ? qi : 0)) * DP);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) qf[cb][ks] = (qi < nq) ? p[4 * ks + g] : v4i{0, 0, 0, 0};
+            if (qi >= nq) phantom |= 1u << cb;
+        }
+        // the class's norm range (whatever the row order is: sortedness only makes it narrow)
+        int kc = 0;
+        unsigned dq[NCB]; // slow classes: this lane's query of block cb has half norm floor(nmin / 2) + dq
+        if (wave_live) {
+            int nmin = INT32_MAX, nmax = 0;
+            for (int qi = q0 + lane; qi < q0 + QPW && qi < nq; qi += 64) {
+                const int v = nrm[it.q_start + qi];
+                nmin = v < nmin ? v : nmin;
+                nmax = v > nmax ? v : nmax;
+            }
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const int a = __shfl_xor(nmin, sh), b = __shfl_xor(nmax, sh);
+                nmin = a < nmin ? a : nmin;
+                nmax = b > nmax ? b : nmax;
+            }
+            const int off = ISX_B3 - (nmin >> 1);
+            kc = __builtin_amdgcn_readfirstlane((off << 5) | cls_id);
+            // a class whose norms spread widely (the two tails of a sorted image, every class of an unsorted one) would
+            // make every row a candidate: it takes the per-value correction instead, which is exact to 1
+            slow = slow || (__builtin_amdgcn_readfirstlane(nmax - nmin) > ISX_PAIR_SPREAD);
+            if (lane == 0) {
+                cls[2 * cls_id] = off;
+                cls[2 * cls_id + 1] = slow ? -1 : 2 * (nmin >> 1) - nmax;
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                const int qi = q0 + cb * 16 + col;
+                dq[cb] = (slow && qi < nq) ? (unsigned)((nrm[it.q_start + qi] >> 1) - (nmin >> 1)) : 0u;
+            }
+        }
+        unsigned m[NCB][2];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) m[cb][0] = m[cb][1] = 0u;
+
+        auto mfma_unit = [&](const Frag &f, v4i (&acc)[NCB]) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[0], qf[cb][0], f.cv, 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[1], qf[cb][1], acc[cb], 0, 0, 0);
+        };
+        // RAG (slow classes: the last, partly filled class of an image and classes of wide norm spread): columns beyond nq
+        // must not reach the row table, and every value is corrected by its own query's half norm -- a select and a
+        // subtraction per value, kept out of the common loop
+        auto run_chunks = [&](auto rag_tag) {
+            constexpr bool RAG = decltype(rag_tag)::value;
+            // tile_c: compile-time tile index in the chunk, -1 .. 7 (-1 = the previous chunk's last tile, or the dummy tile)
+            auto fold_unit = [&](const v4i (&acc)[NCB], unsigned slot_addr, auto tile_c) {
+                constexpr int TB = (decltype(tile_c)::value + 1) * 256;
+                if (!(ISX_PAIR_T & 2))
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++) { // column direction: two max-only streams per column block
+                        m[cb][0] = umax3(m[cb][0], (unsigned)acc[cb][0], (unsigned)acc[cb][2]);
+                        m[cb][1] = umax3(m[cb][1], (unsigned)acc[cb][1], (unsigned)acc[cb][3]);
+                    }
+                if (ISX_PAIR_T & 1) return;
+                unsigned v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { // row direction: max over the class, 16 -> 4 lanes, one correction
+                    unsigned x[NCB];
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++) x[cb] = !RAG ? (unsigned)acc[cb][r] : (phantom & (1u << cb)) ? 0u : (unsigned)acc[cb][r] - dq[cb];
+                    unsigned w = umax3(x[0], x[1], x[2]);
+                    w = umax3(w, x[3], x[4]);
+                    w = umax3(w, x[5], x[6]);
+                    w = w > x[7] ? w : x[7];
+                    w = dpp_quad_max(w);
+                    v[r] = (w << 5) + (unsigned)kc;
+                }
+                // LDS max into the row table from the quad leaders only.  Written as one asm block with the exec mask
+                // switched by hand: a divergent `if` here splits the step into basic blocks and costs 60 VGPRs of spills.
+                if (ISX_PAIR_T & 8) {
+                    asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+                    return;
+                }
+                unsigned long long keep;
+                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %6\n\t"
+                             "ds_max_u32 %1, %2 offset:%7\n\tds_max_u32 %1, %3 offset:%8\n\t"
+                             "ds_max_u32 %1, %4 offset:%9\n\tds_max_u32 %1, %5 offset:%10\n\t"
+                             "s_mov_b64 exec, %0"
+                             : "=&s"(keep)
+                             : "v"(slot_addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(0x1111111111111111ull),
+                               "n"(TB), "n"(TB + 16), "n"(TB + 32), "n"(TB + 48)
+                             : "memory");
+            };
+            v4i accA[NCB], accB[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) accB[cb] = v4i{0, 0, 0, 0};
+            Frag f0, f1;
+            if (wave_live) read_frag(smem, 0, f0);
+            int buf = 0;
+            for (int c = 0; c < n_chunks; c++) {
+                const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
+                if (c + 2 < n_chunks) stage_chunk(c + 2, buf2);
+                const unsigned char *base = smem + buf * BUF;
+                const unsigned slot_addr = row_slot_lds + c * (CHUNK * 16);
+                if (wave_live) {
+                    auto two_tiles = [&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        read_frag(base, t + 1, f1);
+                        mfma_unit(f0, accA);
+                        fold_unit(accB, slot_addr, std::integral_constant<int, t - 1>{});
+                        ISX_STEP_FENCE;
+                        if (t + 2 < 8)
+                            read_frag(base, t + 2, f0);
+                        else
+                            read_frag(smem + buf1 * BUF, 0, f0);
+                        mfma_unit(f1, accB);
+                        fold_unit(accA, slot_addr, std::integral_constant<int, t>{});
+                        ISX_STEP_FENCE;
+                    };
+                    two_tiles(std::integral_constant<int, 0>{});
+                    two_tiles(std::integral_constant<int, 2>{});
+                    two_tiles(std::integral_constant<int, 4>{});
+                    two_tiles(std::integral_constant<int, 6>{});
+                }
+                __syncthreads();
+                buf = buf1;
+            }
+            if (wave_live && n_chunks > 0)
+                fold_unit(accB, row_slot_lds + (n_chunks - 1) * (CHUNK * 16), std::integral_constant<int, 7>{});
+        };
+
+        if (n_chunks > 0) stage_chunk(0, 0);
+        if (n_chunks > 1) stage_chunk(1, 1);
+        __syncthreads();
+        if (slow)
+            run_chunks(std::true_type{});
+        else
+            run_chunks(std::false_type{});
+
+        // column direction of this pass: candidates among this wave's 128 queries
+        if (wave_live) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                unsigned b1 = m[cb][0] > m[cb][1] ? m[cb][0] : m[cb][1];
+                unsigned b2 = m[cb][0] > m[cb][1] ? m[cb][1] : m[cb][0];
+#pragma unroll
+                for (int sh = 16; sh <= 32; sh <<= 1) {
+                    const unsigned o1 = __shfl_xor(b1, sh), o2 = __shfl_xor(b2, sh);
+                    const unsigned mn = b1 > o1 ? o1 : b1, mx2 = b2 > o2 ? b2 : o2;
+                    b1 = b1 > o1 ? b1 : o1;
+                    b2 = mn > mx2 ? mn : mx2;
+                }
+                const int qi = q0 + cb * 16 + col;
+                if (g == 0 && qi < nq && b1 != 0u) {
+                    bool cand = true; // b2 == 0: fewer than two groups saw a train row -- let the exact scan decide
+                    if (b2 != 0u && !(flags & 1)) {
+                        const int na = nrm[it.q_start + qi];
+                        const int s0_hi = na - 2 * ((int)b1 - ISX_B2), s1_hi = na - 2 * ((int)b2 - ISX_B2);
+                        cand = ratio_good(s0_hi > 0 ? s0_hi - 1 : 0, s1_hi, ratio);
+                    }
+                    if (cand) {
+                        const int pos = atomicAdd(&lst[0], 1);
+                        if (pos < ISX_PAIR_CAP) lst[4 + pos] = qi;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // row direction: candidates among the train image's rows, from the table
+    for (int t = tid; t < nt; t += 64 * WAVES) {
+        const uint4 e = ((const uint4 *)rowtab)[t];
+        unsigned a = e.x > e.y ? e.x : e.y, b = e.x > e.y ? e.y : e.x;
+        unsigned c = e.z > e.w ? e.z : e.w, d = e.z > e.w ? e.w : e.z;
+        const unsigned E1 = a > c ? a : c;
+        const unsigned lo = a > c ? c : a, hi2 = b > d ? b : d;
+        const unsigned E2 = lo > hi2 ? lo : hi2;
+        if (E1 == 0u) continue; // no query row at all
+        // entry >> 5 = raw + ISX_B3 - floor(nmin_c / 2), raw = B2 + t.q - ceil(n_t / 2); squared distance s = 2 B2 - p_t - (2 raw - n_q)
+        const int c1 = E1 & 31, c2 = E2 & 31;
+        const int u1 = (int)(E1 >> 5) - ISX_B3, u2 = (int)(E2 >> 5) - ISX_B3; // raw - floor(nmin_c / 2): 2 u >= 2 raw - n_q in the class
+        const int raw2 = (int)(E2 >> 5) - cls[2 * c2];
+        bool cand = true;                                      // fewer than two real entries: the exact scan decides
+        if (E2 != 0u && raw2 >= (1 << 20) && !(flags & 1)) {   // (raw of a real query row is >= 2^20; masked columns give 0)
+            // the two entries belong to two distinct query rows whose 2 raw - n_q is at least 2 u + (2 floor(nmin/2) - nmax)
+            const int lo1 = 2 * u1 + cls[2 * c1 + 1], lo2 = 2 * u2 + cls[2 * c2 + 1];
+            const int lo = lo1 < lo2 ? lo1 : lo2;
+            const int s0_lo = 2 * ISX_B2 - 1 - 2 * u1, s1_hi = 2 * ISX_B2 - lo;
+            cand = ratio_good(s0_lo > 0 ? s0_lo : 0, s1_hi, ratio);
+        }
+        if (cand) {
+            const int pos = atomicAdd(&lst[1], 1);
+            if (pos < ISX_PAIR_CAP) lst[4 + ISX_PAIR_CAP + pos] = t;
+        }
+    }
+    __syncthreads();
+    int n_col = lst[0], n_row = lst[1];
+    if (ISX_PAIR_T & 32) { // timing diagnostic: exactly 16 recounts per direction, whatever the filter found
+        n_col = n_row = 16;
+        if (tid < 16) lst[4 + tid] = lst[4 + ISX_PAIR_CAP + tid] = tid;
+        __syncthreads();
+    }
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    int good_col = 0, good_row = 0;
+    if (n_col <= ISX_PAIR_CAP && !(ISX_PAIR_T & 4))
+        for (int k = wv; k < n_col; k += WAVES) {
+            const int qi = lst[4 + k];
+            int v1, v2;
+            knn2_exact_scan128(desc, nrm, it.q_start + qi, it.t_start, nt, lane, v1, v2);
+            const int na = nrm[it.q_start + qi];
+            good_col += (v1 != INT32_MIN) && (v2 == INT32_MIN || ratio_good(na - v1, na - v2, ratio));
+        }
+    if (n_row <= ISX_PAIR_CAP && !(ISX_PAIR_T & 4))
+        for (int k = wv; k < n_row; k += WAVES) {
+            const int t = lst[4 + ISX_PAIR_CAP + k];
+            int v1, v2;
+            knn2_exact_scan128(desc, nrm, it.t_start + t, it.q_start, nq, lane, v1, v2);
+            const int na = nrm[it.t_start + t];
+            good_row += (v1 != INT32_MIN) && (v2 == INT32_MIN || ratio_good(na - v1, na - v2, ratio));
+        }
+    if (lane == 0) {
+        if (good_col) atomicAdd(&lst[2], good_col);
+        if (good_row) atomicAdd(&lst[3], good_row);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        count_out[2 * (int64_t)item_i] = (ISX_PAIR_T & 16) ? n_col : n_col <= ISX_PAIR_CAP ? lst[2] : -1;
+        count_out[2 * (int64_t)item_i + 1] = (ISX_PAIR_T & 16) ? n_row : n_row <= ISX_PAIR_CAP ? lst[3] : -1;
+    }
+}
+
+extern "C" int isx_knn2_l2_count_pairs(const int8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev, int d_pad,
+                                       const isx_knn_item *items_dev, int n_items, int max_rows, double ratio,
+                                       int32_t *count_out_dev, int flags, void *stream) {
+    ISX_REQUIRE(d_pad == 128, "isx_knn2_l2_count_pairs needs 128-byte rows (got d_pad %d)", d_pad);
+    ISX_REQUIRE(n_items >= 0 && max_rows >= 0, "negative size");
+    ISX_REQUIRE(max_rows <= ISX_PAIR_MAX_ROWS, "isx_knn2_l2_count_pairs takes images of at most %d rows (got %d): use isx_knn2_l2_count_items",
+                ISX_PAIR_MAX_ROWS, max_rows);
+    if (n_items == 0 || max_rows == 0) return ISX_OK;
+    ISX_REQUIRE(desc_dev && nrm_dev && cin_dev && items_dev && count_out_dev, "null device pointer");
+    ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
+    constexpr int WAVES = 8;
+    ISX_HIP_TRY(hipFuncSetAttribute((const void *)knn2_pair_filter_kernel<WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, ISX_PAIR_LDS));
+    const int per = isx_items_per_launch(1, 64 * WAVES);
+    hipStream_t st = (hipStream_t)stream;
+    for (int off = 0; off < n_items; off += per) {
+        const int n = n_items - off < per ? n_items - off : per;
+        hipLaunchKernelGGL((knn2_pair_filter_kernel<WAVES>), dim3((unsigned)n), dim3(64 * WAVES), ISX_PAIR_LDS, st, desc_dev, nrm_dev,
+                           cin_dev, items_dev + off, n, ratio, count_out_dev + 2 * (int64_t)off, flags);
+    }
+    return isx_launch_status("knn2_pair_filter_kernel");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -119,6 +119,78 @@ def prepare_descriptor_tensor(src, starts, counts, check_range=True, wide_ok=Tru
     return PreparedDescriptors(desc, cbase, nrm, cin, starts, counts, d, d_pad, max_norm2, wide)
 
 
+def sort_rows_by_norm(P):
+    """The same prepared set with the rows of every image sorted by norm (ascending).  For the count kernels only: the
+    number of good matches of an image pair does not depend on the row order, and isx_knn2_l2_count_pairs settles more
+    queries without an exact recount when the 128 queries of a class have similar norms.  Needs images stored back to
+    back (starts = cumsum(counts)), which is what prepare_descriptors produces; anything else is returned unchanged."""
+    counts = np.asarray(P.counts, np.int64)
+    starts = np.asarray(P.starts, np.int64)
+    rows = P.desc.shape[0]
+    if len(counts) == 0 or not np.array_equal(starts, np.concatenate([[0], np.cumsum(counts)[:-1]])) or int(counts.sum()) != rows:
+        return P
+    dev = P.device
+    with torch.cuda.device(dev):
+        if len(set(counts.tolist())) == 1:
+            img = torch.arange(rows, device=dev, dtype=torch.int64) // int(counts[0])
+        else:
+            img = torch.repeat_interleave(torch.arange(len(counts), device=dev, dtype=torch.int64),
+                                          torch.from_numpy(counts).to(dev))
+        perm = torch.argsort((img << 32) | P.nrm.to(torch.int64))
+        return PreparedDescriptors(P.desc[perm], P.cbase[perm], P.nrm[perm], P.cin[perm], P.starts, P.counts, P.d, P.d_pad,
+                                   P.max_norm2, P.wide)
+
+
+PAIR_MAX_ROWS = 4096   # isx_knn2_l2_count_pairs: rows per image (its per-row table lives in LDS)
+PAIR_MIN_ITEMS = 2048  # below this many pairs the one-workgroup-per-pair kernel cannot fill the chip: use the directed kernel
+
+
+def pairs_kernel_applies(P, pair_items):
+    """True when the both-directions kernel (isx_knn2_l2_count_pairs) can and should run this pair list."""
+    it = np.asarray(pair_items).reshape(-1, 4)
+    return (not P.wide) and P.d_pad == 128 and len(it) >= PAIR_MIN_ITEMS and int(max(it[:, 1].max(), it[:, 3].max())) <= PAIR_MAX_ROWS
+
+
+def knn2_l2_pairs(P, pair_items, ratio, plan=None, events=None, flags=0, stats=None):
+    """Good-match counts of both directions of unordered image pairs (the loop body of get_collections, reference
+    stitcher.py:285-296) from ONE distance matrix per pair: isx_knn2_l2_count_pairs, then isx_knn2_l2_count_items for
+    the directions it reports as overflowing (overlapping images, more than 128 candidate queries).
+    pair_items: (n,4) int32 rows (q_start, nq, t_start, nt).  Returns (n,2) int32 on the device:
+    [:,0] = len(good) of (query = the q image, train = the t image), [:,1] = the other direction.  Exact counts.
+    stats: optional dict, receives 'overflow_directions'."""
+    L = _lib.lib()
+    dev = P.device
+    with torch.cuda.device(dev):
+        if plan is None:
+            plan = plan_items(pair_items, dev)
+        run_items, perm, items_dev, inv_dev, inv_np = plan
+        m = len(run_items)
+        if m == 0:
+            return torch.zeros((0, 2), dtype=torch.int32, device=dev)
+        max_rows = int(max(run_items[:, 1].max(), run_items[:, 3].max()))
+        counts = torch.empty((m, 2), dtype=torch.int32, device=dev)
+        if events is not None:
+            events[0].record()
+        check(L.isx_knn2_l2_count_pairs(_ptr(P.desc), _ptr(P.nrm), _ptr(P.cin), P.d_pad, _ptr(items_dev), m, max_rows,
+                                        float(ratio), _ptr(counts), int(flags), _stream()))
+        flat = counts.view(-1)
+        over = torch.nonzero(flat < 0).view(-1)          # (host sync: the length of the second stage's item list)
+        n_over = int(over.shape[0])
+        if stats is not None:
+            stats["overflow_directions"] = n_over
+        if n_over:
+            e, d = over >> 1, (over & 1).bool()
+            src = items_dev[e]
+            di = torch.where(d[:, None], src[:, [2, 3, 0, 1]], src).contiguous()
+            c2 = torch.zeros((n_over,), dtype=torch.int32, device=dev)
+            check(L.isx_knn2_l2_count_items(_ptr(P.desc), _ptr(P.nrm), _ptr(P.cin), P.d_pad, _ptr(di), n_over, max_rows,
+                                            float(ratio), _ptr(c2), 0, _stream()))
+            flat[over] = c2
+        if events is not None:
+            events[1].record()
+        return counts[inv_dev] if inv_np is not None else counts
+
+
 TRAIN_GROUP = 4  # train images an XCD keeps resident while it streams query images past them (4 x 512 KiB of its 4 MiB L2)
 
 

@@ -40,6 +40,13 @@ def directed_items(pairs, starts, counts):
     return it
 
 
+def pair_items(pairs, starts, counts):
+    """One work item per unordered pair (i, j) for ops.knn2_l2_pairs: (starts[i], counts[i], starts[j], counts[j]); its
+    result row is (len(good) of i -> j, len(good) of j -> i), the layout of directed_items' counts viewed as (p, 2)."""
+    i, j = pairs[:, 0], pairs[:, 1]
+    return np.stack([starts[i], counts[i], starts[j], counts[j]], 1).astype(np.int32)
+
+
 def components_from_counts(n, pairs, counts_ij, counts_ji, min_match_count, n_union_find=None):
     """Host union-find exactly as stitcher.py:283-300.  The reference visits the ORDERED pairs (i, j) in
     lexicographic order and unions where len(good) >= min_match_count; the same unions are replayed here in

@@ -109,6 +109,22 @@ int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, cons
                             const isx_knn_item *items_dev, int n_items, int max_nq, double ratio,
                             int32_t *count_out_dev, int flags, void *stream);
 
+/* Both directions of UNORDERED image pairs from one distance matrix (round 3): reference stitcher.py:285-296 visits
+ * (i, j) and (j, i); this entry point forms the 128-byte-row products of a pair once (half the matrix instructions of
+ * two isx_knn2_l2_count_items items) and settles almost every query with a max-only filter that proves "not a good
+ * match"; the few candidates are recounted exactly in the kernel.  One work item = one pair: {q_start, nq} = image j,
+ * {t_start, nt} = image i.
+ *   count_out_dev[2 e]     = len(good_matches) of (query = image j, train = image i)
+ *   count_out_dev[2 e + 1] = len(good_matches) of (query = image i, train = image j)
+ *   -1 = that direction has more than 128 candidates (the images overlap): the caller runs it as an item of
+ *        isx_knn2_l2_count_items.  Every other value is the exact count (same as isx_knn2_l2_count_items).
+ * count_out_dev need not be zeroed.  d_pad must be 128 and max_rows (max over items of nq and nt) <= 4096.  Rows sorted
+ * by nrm inside each image keep the candidate lists short (counts do not depend on the row order); any order is exact.
+ * flags bit 0 = test hook: every query is a candidate. */
+int isx_knn2_l2_count_pairs(const int8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev, int d_pad,
+                            const isx_knn_item *items_dev, int n_items, int max_rows, double ratio,
+                            int32_t *count_out_dev, int flags, void *stream);
+
 /* The same matcher without a norm limit: exact L2 kNN-2 + ratio for byte descriptors whose squared distances can
  * leave the range where sqrtf is injective (2*max||v||^2 >= ISX_L2_EXACT_LIMIT: saturated AKAZE / ORB rows).  Ranks on
  * the float32 distances cv2.BFMatcher compares (stitcher.py:85, :115), so squared distances that round to the same

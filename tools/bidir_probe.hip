@@ -7,6 +7,11 @@
 //                             + 8 positions x 4 DPP steps x 4 ops (top-2 across the 16 lanes that hold one train row)
 //                             + 8 ds_write for the cross-wave merge
 //   mode 2  mode 1 without the DPP steps (how much of the cost is the cross-lane part)
+//   mode 3  round 3: both directions with MAX-ONLY FILTER folds (0.5 op per value each way, exact top-2 left to a rescan of
+//           the few "maybe good" queries): 16 MFMA + 16 max3 (column direction, two streams per column block)
+//           + 32 v_sub + 16 ops element-wise max over the column blocks + 8 DPP max (16 lanes of a row -> 4 groups)
+//           + 4 ds_max_u32 into a per-row table in LDS (amounts of the 8-column-block form: DPP and atomics per 8 values)
+//   mode 4  mode 3 without v_sub (norm carried some other way), mode 5 = mode 3 without DPP + atomics
 // Same operand bytes (SIFT-like), every CU busy, 3 waves per SIMD as the kernel: the number printed is ns per unit
 // per SIMD, directly comparable with the kernel's 185 ns per directed unit.
 // Build: hipcc --offload-arch=gfx950 -O3 tools/bidir_probe.hip -o tools/bin/bidir_probe
@@ -25,6 +30,8 @@ __device__ __forceinline__ int rnd(int x) {
 template <int MODE>
 __global__ void __launch_bounds__(256, 3) probe(int iters, unsigned *out) {
     __shared__ unsigned lds[4][64];
+    __shared__ unsigned rowtab[128][4];
+    if (MODE >= 3) { for (int i = threadIdx.x; i < 512; i += 256) (&rowtab[0][0])[i] = 0; __syncthreads(); }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     v4i a[2][2], q[4][2], cv[2];
     for (int t = 0; t < 2; t++) for (int k = 0; k < 2; k++) for (int e = 0; e < 4; e++) a[t][k][e] = rnd(lane * 131 + t * 17 + k * 5 + e);
@@ -46,6 +53,43 @@ __global__ void __launch_bounds__(256, 3) probe(int iters, unsigned *out) {
 #pragma unroll
                 for (int c = 0; c < 4; c++) X[t][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][1], q[c][1], X[t][c], 0, 0, 0);
             }
+            if (MODE >= 3) {
+                // column direction, filter form: two max-only streams per column block (16 ops for 32 values)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(m[c][0]) : "v"(Y[t][c][0]), "v"(Y[t][c][1]));
+                        asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(m[c][1]) : "v"(Y[t][c][2]), "v"(Y[t][c][3]));
+                    }
+                if (MODE != 4)
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(Y[t][c][r]) : "v"(qn[c]));
+                // row direction: element-wise max over the column blocks (2 ops per 4 values), running over both halves
+                // of the iteration as the 8-column-block kernel would (rr persists; reduced + flushed every second half)
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        unsigned mx;
+                        asm volatile("v_max3_u32 %0, %1, %2, %3" : "=v"(mx) : "v"(Y[t][0][r]), "v"(Y[t][1][r]), "v"(Y[t][2][r]));
+                        if (half == 0) asm volatile("v_max_u32 %0, %1, %2" : "=v"(G[r]) : "v"(mx), "v"(Y[t][3][r]));   // (G, qn reused as scratch state)
+                        else asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(G[r]) : "v"(mx), "v"(Y[t][3][r]));
+                        if (MODE != 5 && half == 1 && t == 1) {
+                            asm volatile("v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(G[r]));
+                            asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(G[r]));
+                        }
+                    }
+                if (MODE != 5 && half == 1) {
+                    if ((lane & 3) == 0)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) atomicMax(&rowtab[((it * 4 + r) & 7) * 16 + (lane >> 4) * 4 + r][(lane >> 2) & 3], G[r]);
+                }
+            } else
             // column direction: the kernel's fold (40 ops)
 #pragma unroll
             for (int c = 0; c < 4; c++)
@@ -58,7 +102,7 @@ __global__ void __launch_bounds__(256, 3) probe(int iters, unsigned *out) {
                     asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(m[c][r + 1]) : "v"(Y[0][c][r + 1]), "v"(Y[1][c][r + 1]));
                     asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(G[c]) : "v"(t0), "v"(t1));
                 }
-            if (MODE >= 1) {
+            if (MODE == 1 || MODE == 2) {
                 // row direction.  (a) symmetric value: subtract the query's half norm (32 ops)
                 v4i (&S)[2][4] = Y; // in place: the fold above was the last reader of the raw values
 #pragma unroll
@@ -113,6 +157,7 @@ __global__ void __launch_bounds__(256, 3) probe(int iters, unsigned *out) {
     for (int c = 0; c < 4; c++) { acc ^= G[c]; for (int r = 0; r < 4; r++) acc ^= m[c][r]; }
     for (int t = 0; t < 2; t++) for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) acc ^= (unsigned)accA[t][c][r] ^ (unsigned)accB[t][c][r];
     acc ^= lds[wave][lane];
+    if (MODE >= 3) { __syncthreads(); acc ^= rowtab[threadIdx.x & 127][lane & 3] ^ qn[0]; }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
@@ -134,9 +179,13 @@ int main() {
     unsigned *out; CK(hipMalloc(&out, blocks * 256 * 4));
     const int iters = 20000;
     const double a = run<0>(iters, out, blocks), b = run<1>(iters, out, blocks), c = run<2>(iters, out, blocks);
+    const double d3 = run<3>(iters, out, blocks), d4 = run<4>(iters, out, blocks), d5 = run<5>(iters, out, blocks);
     printf("ns per unit per SIMD  (kernel today: ~185 ns per DIRECTED unit)\n");
     printf("  mode 0  two-pass ingredients (16 MFMA + 40 fold)             %7.1f ns   -> %7.1f ns per unordered unit (x2)\n", a, 2 * a);
     printf("  mode 1  both directions (+32 sub +40 top2-of-4 +128 DPP +LDS) %7.1f ns per unordered unit  = %.2fx of two-pass\n", b, b / (2 * a));
     printf("  mode 2  mode 1 without the DPP lane reduction                %7.1f ns per unordered unit  = %.2fx of two-pass\n", c, c / (2 * a));
+    printf("  mode 3  both directions, max-only filter folds (+sub +DPP +LDS atomics) %7.1f ns per unordered unit  = %.2fx of two-pass\n", d3, d3 / (2 * a));
+    printf("  mode 4  mode 3 without the norm subtraction                  %7.1f ns per unordered unit  = %.2fx of two-pass\n", d4, d4 / (2 * a));
+    printf("  mode 5  mode 3 without DPP + LDS atomics                     %7.1f ns per unordered unit  = %.2fx of two-pass\n", d5, d5 / (2 * a));
     return 0;
 }
