@@ -1324,9 +1324,8 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
 #define ISX_PAIR_CAP 128
 #define ISX_PAIR_SPREAD 16384 /* norm spread of a class (128 query rows) beyond which it takes the per-value correction */
 #ifndef ISX_PAIR_T
-#define ISX_PAIR_T 0 /* compile-time timing diagnostics (tools/build_variant.sh), results WRONG when != 0: 1 no row-direction fold,
-                        2 no column fold, 4 no exact recounts, 8 row fold without its LDS atomics, 16 report the candidate counts,
-                        32 exactly 16 recounts per direction */
+#define ISX_PAIR_T 0 /* compile-time timing diagnostics (tools/build_variant.sh), results WRONG when != 0: 4 no exact recounts,
+                        16 report the candidate counts, 32 exactly 16 recounts per direction, 64 no chunk barrier */
 #endif
 #define ISX_PAIR_MAX_ROWS 4096
 #define ISX_B3 (1 << 22) /* bias of the packed row-direction bound: keeps it positive */
@@ -1387,36 +1386,38 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_desc, (lds_ptr_t)(smem_lds + bufi * BUF + piece * 1024), 16, lane_voff,
                                                      c * (CHUNK * DP) + piece * 1024, 0, 0);
         }
-        if (wv < 2)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cin, (lds_ptr_t)(smem_lds + bufi * BUF + CHUNK * DP + wv * 256), 4,
-                                                     lane * 4, c * (CHUNK * 4) + wv * 256, 0, 0);
+        // every wave loads one of the two cin pieces (the same bytes up to four times): each wave then has exactly
+        // PPW + 1 DMA instructions per stage in flight, which the counted wait before the chunk barrier relies on
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cin, (lds_ptr_t)(smem_lds + bufi * BUF + CHUNK * DP + (wv & 1) * 256), 4,
+                                                 lane * 4, c * (CHUNK * 4) + (wv & 1) * 256, 0, 0);
     };
+    static_assert(PIECES % WAVES == 0 && PPW + 1 == 3, "the counted waits below assume 3 DMA instructions per wave and stage");
 #pragma clang diagnostic pop
     struct Frag {
         v4i a[2];
         v4i cv;
     };
-    auto read_frag = [&](const unsigned char *base, int t, Frag &f) {
-        const int row = t * 16 + col;
-#pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            const int slot = 4 * ks + g;
-            f.a[ks] = *(const v4i *)(base + row * DP + ((slot ^ ((row >> SH) & (SLOTS - 1))) << 4));
-        }
-        f.cv = *(const v4i *)(base + CHUNK * DP + (t * 16 + 4 * g) * 4);
+    // Fragment addresses: row = 16 t + col and the XOR swizzle ((row >> 1) & 7) = ((col >> 1) & 7) does not depend on the
+    // tile, so a lane's three addresses are (buffer base + a per-lane constant) + an immediate per tile -- no address
+    // arithmetic in the loop.
+    const unsigned fo0 = col * DP + (((unsigned)g ^ ((col >> SH) & (SLOTS - 1))) << 4);
+    const unsigned fo1 = col * DP + (((unsigned)(4 + g) ^ ((col >> SH) & (SLOTS - 1))) << 4);
+    const unsigned foc = CHUNK * DP + 16 * g;
+    auto read_frag = [&](const unsigned char *base, auto tc, Frag &f) {
+        constexpr int t = decltype(tc)::value;
+        f.a[0] = *(const v4i *)(base + fo0 + t * (16 * DP));
+        f.a[1] = *(const v4i *)(base + fo1 + t * (16 * DP));
+        f.cv = *(const v4i *)(base + foc + t * 64);
     };
     // this lane's slot of the row table for register 0 of tile 0 of chunk 0 (quad leaders write): row 4g, group (lane>>2)&3
     // as an LDS byte address, one tile back (the dummy tile): the fold adds (tile + 1) * 256 + 16 r as an immediate
     const unsigned row_slot_lds = smem_lds + 3 * BUF + ((4 * g) * 4 + ((lane >> 2) & 3)) * 4;
 
-    for (int pass = 0; pass < n_pass; pass++) {
+    v4i qf[NCB][2];
+    unsigned phantom = 0; // bit cb: this lane's column of block cb is beyond nq
+    auto load_queries = [&](int pass) {
         const int q0 = pass * QPB + wave * QPW;
-        const bool wave_live = q0 < nq;
-        const bool ragged = q0 + QPW > nq;
-        bool slow = ragged; // this class folds the row direction with one correction per VALUE (below)
-        const int cls_id = pass * WAVES + wave;
-        v4i qf[NCB][2];
-        unsigned phantom = 0; // bit cb: this lane's column of block cb is beyond nq
+        phantom = 0;
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) {
             const int qi = q0 + cb * 16 + col;
@@ -1425,9 +1426,22 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             for (int ks = 0; ks < 2; ks++) qf[cb][ks] = (qi < nq) ? p[4 * ks + g] : v4i{0, 0, 0, 0};
             if (qi >= nq) phantom |= 1u << cb;
         }
+    };
+    load_queries(0);
+    if (n_chunks > 0) stage_chunk(0, 0);
+    if (n_chunks > 1) stage_chunk(1, 1);
+
+    for (int pass = 0; pass < n_pass; pass++) {
+        const int q0 = pass * QPB + wave * QPW;
+        const bool wave_live = q0 < nq;
+        const int cls_id = pass * WAVES + wave;
+        // 0: the common class.  1: wide norm spread -- every value is corrected by its own query's half norm (one
+        // subtraction per value).  2: the last, partly filled class of an image -- as 1, and the columns beyond nq are
+        // kept out of the row table (a select per value).  1 and 2 are kept out of the common loop.
+        int mode = q0 + QPW > nq ? 2 : 0;
         // the class's norm range (whatever the row order is: sortedness only makes it narrow)
         int kc = 0;
-        unsigned dq[NCB]; // slow classes: this lane's query of block cb has half norm floor(nmin / 2) + dq
+        unsigned dq[NCB]; // modes 1, 2: this lane's query of block cb has half norm floor(nmin / 2) + dq
         if (wave_live) {
             int nmin = INT32_MAX, nmax = 0;
             for (int qi = q0 + lane; qi < q0 + QPW && qi < nq; qi += 64) {
@@ -1445,76 +1459,101 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             kc = __builtin_amdgcn_readfirstlane((off << 5) | cls_id);
             // a class whose norms spread widely (the two tails of a sorted image, every class of an unsorted one) would
             // make every row a candidate: it takes the per-value correction instead, which is exact to 1
-            slow = slow || (__builtin_amdgcn_readfirstlane(nmax - nmin) > ISX_PAIR_SPREAD);
+            if (mode == 0 && __builtin_amdgcn_readfirstlane(nmax - nmin) > ISX_PAIR_SPREAD) mode = 1;
             if (lane == 0) {
                 cls[2 * cls_id] = off;
-                cls[2 * cls_id + 1] = slow ? -1 : 2 * (nmin >> 1) - nmax;
+                cls[2 * cls_id + 1] = mode ? -1 : 2 * (nmin >> 1) - nmax;
             }
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
                 const int qi = q0 + cb * 16 + col;
-                dq[cb] = (slow && qi < nq) ? (unsigned)((nrm[it.q_start + qi] >> 1) - (nmin >> 1)) : 0u;
+                dq[cb] = (mode && qi < nq) ? (unsigned)((nrm[it.q_start + qi] >> 1) - (nmin >> 1)) : 0u;
             }
         }
         unsigned m[NCB][2];
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) m[cb][0] = m[cb][1] = 0u;
 
-        auto mfma_unit = [&](const Frag &f, v4i (&acc)[NCB]) {
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[0], qf[cb][0], f.cv, 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < NCB; cb++) acc[cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[1], qf[cb][1], acc[cb], 0, 0, 0);
-        };
-        // RAG (slow classes: the last, partly filled class of an image and classes of wide norm spread): columns beyond nq
-        // must not reach the row table, and every value is corrected by its own query's half norm -- a select and a
-        // subtraction per value, kept out of the common loop
-        auto run_chunks = [&](auto rag_tag) {
-            constexpr bool RAG = decltype(rag_tag)::value;
-            // tile_c: compile-time tile index in the chunk, -1 .. 7 (-1 = the previous chunk's last tile, or the dummy tile)
-            auto fold_unit = [&](const v4i (&acc)[NCB], unsigned slot_addr, auto tile_c) {
+        auto run_chunks = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            // One step = the 16 matrix instructions of tile X interleaved BY HAND with the fold of the previous tile P (44
+            // vector ops + 4 LDS atomics), three vector ops in the shadow of each matrix instruction: a wave that is left
+            // to the scheduler issues its fold in blocks, and with two lock-stepped waves per SIMD the matrix pipe then
+            // idles while both fold (counters: matrix pipe 51 % busy, 16 % of the cycles co-issued).
+            // tile_c: compile-time index of tile P in the chunk, -1 .. 7 (-1 = the previous chunk's last tile, or the dummy tile)
+            auto step = [&](const Frag &f, v4i (&X)[NCB], const v4i (&P)[NCB], unsigned slot_addr, auto tile_c) {
                 constexpr int TB = (decltype(tile_c)::value + 1) * 256;
-                if (!(ISX_PAIR_T & 2))
+                auto x = [&](int cb, int r) -> unsigned { // value of P for the row direction
+                    unsigned v = (unsigned)P[cb][r];
+                    if (MODE >= 1) v -= dq[cb];
+                    if (MODE == 2) v = (phantom & (1u << cb)) ? 0u : v;
+                    return v;
+                };
+                unsigned w[4];
+                const int kcl = kc; // (a plain use: clang does not capture a variable that only appears as an asm operand)
 #pragma unroll
-                    for (int cb = 0; cb < NCB; cb++) { // column direction: two max-only streams per column block
-                        m[cb][0] = umax3(m[cb][0], (unsigned)acc[cb][0], (unsigned)acc[cb][2]);
-                        m[cb][1] = umax3(m[cb][1], (unsigned)acc[cb][1], (unsigned)acc[cb][3]);
+                for (int k = 0; k < 8; k++) {
+                    X[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[0], qf[k][0], f.cv, 0, 0, 0);
+                    // column direction: two max-only streams per column block
+                    m[k][0] = umax3(m[k][0], (unsigned)P[k][0], (unsigned)P[k][2]);
+                    m[k][1] = umax3(m[k][1], (unsigned)P[k][1], (unsigned)P[k][3]);
+                    // row direction: max over the class's 8 column blocks, register r = k & 3
+                    if (k < 4)
+                        w[k] = umax3(x(0, k), x(1, k), x(2, k));
+                    else
+                        w[k - 4] = umax3(w[k - 4], x(3, k - 4), x(4, k - 4));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    X[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[1], qf[k][1], X[k], 0, 0, 0);
+                    if (k < 2) {
+                        w[2 * k] = umax3(w[2 * k], x(5, 2 * k), x(6, 2 * k));
+                        w[2 * k + 1] = umax3(w[2 * k + 1], x(5, 2 * k + 1), x(6, 2 * k + 1));
+                    } else if (k < 4) {
+                        const int r = 2 * (k - 2);
+                        const unsigned a7 = x(7, r), b7 = x(7, r + 1);
+                        w[r] = w[r] > a7 ? w[r] : a7;
+                        w[r + 1] = w[r + 1] > b7 ? w[r + 1] : b7;
+                    } else if (k == 4) { // 16 -> 4 lanes: two DPP maxima over the quads (the four chains interleave: no wait states)
+                        asm volatile("v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_max_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_max_u32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_max_u32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+                    } else if (k == 5) {
+                        asm volatile("v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_max_u32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_max_u32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_max_u32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+                    } else if (k == 6) {
+                        // the class's correction and tag, then the LDS max into the row table from the quad leaders only; the
+                        // exec mask is switched by hand (a divergent `if` here splits the step into basic blocks and costs
+                        // 60 VGPRs of spills)
+                        unsigned long long keep;
+                        asm volatile("v_lshl_add_u32 %1, %1, 5, %6\n\t"
+                                     "v_lshl_add_u32 %2, %2, 5, %6\n\t"
+                                     "v_lshl_add_u32 %3, %3, 5, %6\n\t"
+                                     "v_lshl_add_u32 %4, %4, 5, %6\n\t"
+                                     "s_mov_b64 %0, exec\n\t"
+                                     "s_mov_b64 exec, %7\n\t"
+                                     "ds_max_u32 %5, %1 offset:%8\n\tds_max_u32 %5, %2 offset:%9\n\t"
+                                     "ds_max_u32 %5, %3 offset:%10\n\tds_max_u32 %5, %4 offset:%11\n\t"
+                                     "s_mov_b64 exec, %0"
+                                     : "=&s"(keep), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])
+                                     : "v"(slot_addr), "s"(kcl), "s"(0x1111111111111111ull),
+                                       "n"(TB), "n"(TB + 16), "n"(TB + 32), "n"(TB + 48)
+                                     : "memory");
                     }
-                if (ISX_PAIR_T & 1) return;
-                unsigned v[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) { // row direction: max over the class, 16 -> 4 lanes, one correction
-                    unsigned x[NCB];
-#pragma unroll
-                    for (int cb = 0; cb < NCB; cb++) x[cb] = !RAG ? (unsigned)acc[cb][r] : (phantom & (1u << cb)) ? 0u : (unsigned)acc[cb][r] - dq[cb];
-                    unsigned w = umax3(x[0], x[1], x[2]);
-                    w = umax3(w, x[3], x[4]);
-                    w = umax3(w, x[5], x[6]);
-                    w = w > x[7] ? w : x[7];
-                    w = dpp_quad_max(w);
-                    v[r] = (w << 5) + (unsigned)kc;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // LDS max into the row table from the quad leaders only.  Written as one asm block with the exec mask
-                // switched by hand: a divergent `if` here splits the step into basic blocks and costs 60 VGPRs of spills.
-                if (ISX_PAIR_T & 8) {
-                    asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-                    return;
-                }
-                unsigned long long keep;
-                asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %6\n\t"
-                             "ds_max_u32 %1, %2 offset:%7\n\tds_max_u32 %1, %3 offset:%8\n\t"
-                             "ds_max_u32 %1, %4 offset:%9\n\tds_max_u32 %1, %5 offset:%10\n\t"
-                             "s_mov_b64 exec, %0"
-                             : "=&s"(keep)
-                             : "v"(slot_addr), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "s"(0x1111111111111111ull),
-                               "n"(TB), "n"(TB + 16), "n"(TB + 32), "n"(TB + 48)
-                             : "memory");
             };
             v4i accA[NCB], accB[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) accB[cb] = v4i{0, 0, 0, 0};
             Frag f0, f1;
-            if (wave_live) read_frag(smem, 0, f0);
+            if (wave_live) read_frag(smem, std::integral_constant<int, 0>{}, f0);
             int buf = 0;
             for (int c = 0; c < n_chunks; c++) {
                 const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
@@ -1524,37 +1563,50 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 if (wave_live) {
                     auto two_tiles = [&](auto tc) {
                         constexpr int t = decltype(tc)::value;
-                        read_frag(base, t + 1, f1);
-                        mfma_unit(f0, accA);
-                        fold_unit(accB, slot_addr, std::integral_constant<int, t - 1>{});
-                        ISX_STEP_FENCE;
+                        read_frag(base, std::integral_constant<int, t + 1>{}, f1);
+                        step(f0, accA, accB, slot_addr, std::integral_constant<int, t - 1>{});
                         if (t + 2 < 8)
-                            read_frag(base, t + 2, f0);
+                            read_frag(base, std::integral_constant<int, (t + 2) & 7>{}, f0);
                         else
-                            read_frag(smem + buf1 * BUF, 0, f0);
-                        mfma_unit(f1, accB);
-                        fold_unit(accA, slot_addr, std::integral_constant<int, t>{});
-                        ISX_STEP_FENCE;
+                            read_frag(smem + buf1 * BUF, std::integral_constant<int, 0>{}, f0);
+                        step(f1, accB, accA, slot_addr, std::integral_constant<int, t>{});
                     };
                     two_tiles(std::integral_constant<int, 0>{});
                     two_tiles(std::integral_constant<int, 2>{});
                     two_tiles(std::integral_constant<int, 4>{});
                     two_tiles(std::integral_constant<int, 6>{});
                 }
-                __syncthreads();
+                // chunk c + 1 must have landed and every wave must be done with chunk c.  A __syncthreads() here waits for
+                // ALL memory operations (vmcnt(0)), i.e. also for chunk c + 2, issued a moment ago; wait for all but the
+                // newest stage instead.  The LDS reads of chunk c were consumed by this iteration's matrix instructions,
+                // the table atomics are only read after the last pass.
+                if (ISX_PAIR_T & 64)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (timing diagnostic: no chunk barrier)
+                else if (c + 2 < n_chunks)
+                    asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 buf = buf1;
             }
+            // drain: fold the last tile (the matrix instructions of this extra step run on stale fragments into accA, unused)
             if (wave_live && n_chunks > 0)
-                fold_unit(accB, row_slot_lds + (n_chunks - 1) * (CHUNK * 16), std::integral_constant<int, 7>{});
+                step(f0, accA, accB, row_slot_lds + (n_chunks - 1) * (CHUNK * 16), std::integral_constant<int, 7>{});
         };
 
-        if (n_chunks > 0) stage_chunk(0, 0);
-        if (n_chunks > 1) stage_chunk(1, 1);
-        __syncthreads();
-        if (slow)
-            run_chunks(std::true_type{});
+        __syncthreads(); // the first two chunks of this pass have landed (staged before the previous pass's epilogue)
+        if (mode == 0)
+            run_chunks(std::integral_constant<int, 0>{});
+        else if (mode == 1)
+            run_chunks(std::integral_constant<int, 1>{});
         else
-            run_chunks(std::false_type{});
+            run_chunks(std::integral_constant<int, 2>{});
+        // every wave is past the last chunk's barrier: the buffers are free.  Start the next pass's first chunks and query
+        // rows now, so that they travel while this pass's column results are evaluated.
+        if (pass + 1 < n_pass) {
+            if (n_chunks > 0) stage_chunk(0, 0);
+            if (n_chunks > 1) stage_chunk(1, 1);
+            load_queries(pass + 1);
+        }
 
         // column direction of this pass: candidates among this wave's 128 queries
         if (wave_live) {
