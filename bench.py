@@ -8,15 +8,15 @@ Workload (BASELINE.json configs[2], the configuration the metric "image pairs ma
 is quoted on; it fits one GPU): ArbitraryStitcher.get_collections over 512 shuffled crops x 4096
 SIFT-like keypoints (integer-valued 128-d descriptors, 8 planted scenes of 64 overlapping images,
 SURVEY.md section 8d).  One STEP = one full all-pairs pass: [all_gather of the per-rank descriptor
-shards over RCCL when N>1] -> descriptor preparation -> ONE fused kNN-2 + Lowe-ratio launch over both
-directions of this rank's share of the 130,816 unordered pairs -> gather of the int32 good-match
-counts -> host union-find on rank 0.  Inputs (the raw uint8 descriptor shard) are resident in HBM
+shards over RCCL when N>1] -> descriptor preparation (+ rows sorted by norm) -> fused kNN-2 + Lowe-ratio
+counts of both directions of this rank's share of the 130,816 unordered pairs (one launch over all pairs,
+one over the overlapping ones) -> gather of the int32 good-match counts -> host union-find on rank 0.  Inputs (the raw uint8 descriptor shard) are resident in HBM
 when the timed region starts.  The pair space is fixed and split over the ranks => "scaling":
 "strong".
 
 The JSON line also carries:
-  roofline     -- the dominant kernel (knn2_count16w_kernel) against the dense int8 MFMA peak, from the
-                  kernel duration measured live with HIP events around the launch;
+  roofline     -- the dominant kernel (knn2_pair_filter_kernel, with the second-stage launch it hands the overlapping
+                  pairs to) against the dense int8 MFMA peak, from the duration measured live with HIP events;
   cpu_baseline -- the CPU oracle's port of cv2.BFMatcher().knnMatch(float32) + ratio loop, timed on
                   a bounded sample of the same pairs on this host (rank 0, N=1 only);
   stitch       -- (N=1 only, skip with --no-stitch) the second half of BASELINE.json's metric, "HD
@@ -300,7 +300,12 @@ def main():
     counts = np.full((n,), kp, np.int64)
     all_pairs = prs.unordered_pairs(n)
     my_pairs = prs.shard_pairs(all_pairs, rank, world)
-    plan = ops.plan_items(prs.directed_items(my_pairs, starts, counts), dev)
+    # one work item per unordered pair: isx_knn2_l2_count_pairs forms a pair's 4096 x 4096 products once for both directions
+    # (max-only filter + exact recount of the candidates); the directions it reports as overflowing (overlapping images)
+    # run on the two-pass kernel isx_knn2_l2_count_items inside the same step.  ISX_BENCH_TWO_PASS=1: round 2's path.
+    two_pass = os.environ.get("ISX_BENCH_TWO_PASS") == "1"
+    plan = ops.plan_items(prs.directed_items(my_pairs, starts, counts) if two_pass else prs.pair_items(my_pairs, starts, counts), dev)
+    stage = {}
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]  # step start | after all_gather | after kernel | after gather
     kernel_ms, parts = [], []
@@ -313,7 +318,10 @@ def main():
         if record:
             marks[1].record()
         P = ops.prepare_descriptor_tensor(full.reshape(-1, d), starts, counts)
-        c = ops.knn2_l2_items(P, None, ratio, plan=plan, events=ev if record else None)
+        if two_pass:
+            c = ops.knn2_l2_items(P, None, ratio, plan=plan, events=ev if record else None)
+        else:
+            c = ops.knn2_l2_pairs(ops.sort_rows_by_norm(P), None, ratio, plan=plan, events=ev if record else None, stats=stage)
         if record:
             marks[2].record()
         allc = prs.gather_counts(c.view(-1, 2), len(all_pairs), rank, world)
@@ -380,10 +388,16 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         ops_per_launch = 2.0 * kp * kp * d * len(my_pairs)  # 2*Nq*Nt*D per unordered pair
         achieved = ops_per_launch / (k_ms * 1e-3) / 1e12
-        traffic = None
+        # roofline.traffic is NOT measured in this run: it is the PMC figure (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)
+        # committed under profiles/ for the kernel launched here on this very workload, or null when there is none
+        kernel_name = "knn2_count16w_kernel" if two_pass else "knn2_pair_filter_kernel"
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "knn2_traffic.json")
         if os.path.exists(tf) and world == 1 and (args.scenes, args.imgs_per_scene, kp) == (8, 64, 4096):
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            ent = json.load(open(tf)).get("kernels", {}).get(kernel_name)
+            if ent:
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/knn2_traffic.json [{kernel_name}], {ent.get('measured')}: not measured in this run"
         line = {
             "metric": "image pairs matched/sec (SIFT 4k kp)",
             "value": pairs_per_step * args.steps / elapsed,
@@ -400,9 +414,16 @@ def main():
                        "pairs_per_step": pairs_per_step, "parallelism": f"pair-sharded x{world}",
                        "components_correct": bool(ok)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
-                         "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic,
-                         "kernel": "knn2_count16w_kernel", "kernel_ms": k_ms,
-                         "note": "int8 MFMA ops; algorithmic 2*Nq*Nt*D per unordered pair (the kernel executes 2x: one pass per direction)"},
+                         "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": kernel_name,
+                         "kernel_ms": k_ms,
+                         "note": "int8 MFMA ops; algorithmic 2*Nq*Nt*D per unordered pair (the kernel executes 2x: one pass per direction)"
+                                 if two_pass else
+                                 "int8 MFMA ops; algorithmic 2*Nq*Nt*D per unordered pair.  kernel_ms spans BOTH launches of a step between "
+                                 "two HIP events: knn2_pair_filter_kernel over every pair (one distance matrix per pair) and "
+                                 f"knn2_count16w_kernel over the {stage.get('overflow_directions')} of {2 * len(my_pairs)} directions the filter "
+                                 "reports as overflowing (overlapping images), incl. the list compaction between them",
+                         "overflow_directions": None if two_pass else stage.get("overflow_directions")},
         }
         line["step_breakdown"] = breakdown
         if world == 1 and not args.no_cpu_baseline:

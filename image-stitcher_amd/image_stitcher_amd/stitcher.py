@@ -30,7 +30,7 @@ from .async_save import AsyncImageWriter, write_image
 from .detect import make_detector
 from .device_image import DeviceImage, MosaicArena
 from .strips import StripMosaic
-from .pairs import components_from_counts, directed_items, gather_counts, shard_pairs, unordered_pairs
+from .pairs import components_from_counts, directed_items, gather_counts, pair_items, shard_pairs, unordered_pairs
 from .utils.logger import LogWrapper
 from .utils.proc import (crop_image, get_corners_from_image, get_padded_images, get_roi_from_corners,  # noqa: F401
                          load_image, resize_image, seamless_gradient_merge, seamless_merge,
@@ -768,8 +768,14 @@ class ArbitraryStitcher(Stitcher):
             if kind == "int":
                 try:
                     P = ops.prepare_descriptors(self.des, device=dev)
-                    items = directed_items(mine, P.starts, P.counts)
-                    c = ops.knn2_l2_items(P, items, self.lowes_ratio_threshold).view(-1, 2)
+                    pitems = pair_items(mine, np.asarray(P.starts), np.asarray(P.counts))
+                    if ops.pairs_kernel_applies(P, pitems):
+                        # both directions of a pair from one distance matrix (isx_knn2_l2_count_pairs); counts do not
+                        # depend on the row order, so the rows are sorted by norm first (short candidate lists)
+                        c = ops.knn2_l2_pairs(ops.sort_rows_by_norm(P), pitems, self.lowes_ratio_threshold)
+                    else:
+                        items = directed_items(mine, P.starts, P.counts)
+                        c = ops.knn2_l2_items(P, items, self.lowes_ratio_threshold).view(-1, 2)
                 except ops.NotIntegerValuedError:
                     kind = "f32"  # see get_matches
             if kind != "int":
@@ -777,10 +783,13 @@ class ArbitraryStitcher(Stitcher):
                 c = ops.alt_item_counts(des, lambda st, ct: directed_items(mine, st, ct), kind,
                                         self.lowes_ratio_threshold, dev).view(-1, 2)
             allc = gather_counts(c, len(pairs), rank, world, self.dist_group)
-            if world > 1:
-                box = [allc.cpu().numpy() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0, group=self.dist_group)
-                counts = box[0]
+            if world > 1:  # every rank runs the union-find: the counts go out as one tensor broadcast (RCCL on GPUs)
+                if rank != 0:
+                    allc = torch.empty((len(pairs), 2), dtype=torch.int32, device=c.device)
+                allc = allc.contiguous()
+                dist.broadcast(allc, src=dist.get_global_rank(self.dist_group, 0) if self.dist_group is not None else 0,
+                               group=self.dist_group)
+                counts = allc.cpu().numpy()
             else:
                 counts = allc.cpu().numpy()
         return pairs, counts
