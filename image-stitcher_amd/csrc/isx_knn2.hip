@@ -1586,6 +1586,9 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                     asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef ISX_PAIR_SKEW
+                if (wave >= WAVES / 2) __builtin_amdgcn_s_sleep(ISX_PAIR_SKEW);
+#endif
                 buf = buf1;
             }
             // drain: fold the last tile (the matrix instructions of this extra step run on stale fragments into accA, unused)
