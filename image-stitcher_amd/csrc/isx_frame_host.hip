@@ -50,15 +50,13 @@ extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const v
     const size_t elem = dtype == ISX_U8 ? 1 : 4;
     // raw rows as uploaded: L2 keeps the caller's width (isx_desc_prep pads), Hamming is padded on the way in
     const size_t raw_row = norm == ISX_NORM_HAMMING ? (size_t)d_pad : (size_t)d * elem;
-    // One pair on the whole chip: the L2 index kernel takes (query block x train segment) work items -- the train set is
-    // cut into up to FM_MAX_SEG segments of a multiple of 128 rows (the kernel's staging chunk) and the per-segment
-    // results are merged in the compaction kernel (isx_ratio_compact_segments).  With query blocks alone a 1500 x 1500
-    // pair runs on 6 workgroups that each scan every train row (22 us, latency-bound).
-    int n_seg = 1, seg_rows = nt;
-    if (norm == ISX_NORM_L2) {
-        seg_rows = 128 * ((nt + 128 * FM_MAX_SEG - 1) / (128 * FM_MAX_SEG));
-        n_seg = (nt + seg_rows - 1) / seg_rows;
-    }
+    // One pair on the whole chip: both index kernels (L2 and Hamming) take (query block x train segment) work items --
+    // the train set is cut into up to FM_MAX_SEG segments of a multiple of 128 rows (the L2 kernel's staging chunk) and
+    // the per-segment results are merged under (distance, train index) in the compaction kernel
+    // (isx_ratio_compact_segments).  With query blocks alone a 1500 x 1500 pair runs on 6 workgroups that each scan
+    // every train row (22 us, latency-bound).
+    const int seg_rows = 128 * ((nt + 128 * FM_MAX_SEG - 1) / (128 * FM_MAX_SEG));
+    const int n_seg = (nt + seg_rows - 1) / seg_rows;
     // block layout (device and pinned mirror): [header 512][raw rows][-- device only below --]
     //   header: isx_knn_item[16] (256) | out_start int64[16] (128) | count int32[16] (64) | stats int32[2] | compact count int32
     const size_t o_raw = FM_H_BYTES, o_desc = o_raw + up256(raw_row * rows), o_cbase = o_desc + up256((size_t)d_pad * rows);
@@ -92,7 +90,7 @@ extern "C" int isx_frame_match(isx_ctx *ctx, const void *q_host, int nq, const v
     int32_t *idx_dev = (int32_t *)(D + o_idx);
     float *dist_dev = (float *)(D + o_dist);
     if (norm == ISX_NORM_HAMMING) {
-        rc = isx_knn2_hamming_items(D + o_raw, d_pad, items_dev, 1, nq, nt, ratio, idx_dev, dist_dev, out_start_dev, count_dev, st);
+        rc = isx_knn2_hamming_items(D + o_raw, d_pad, items_dev, n_seg, nq, seg_rows, ratio, idx_dev, dist_dev, out_start_dev, count_dev, st);
     } else {
         rc = isx_desc_prep(D + o_raw, dtype, rows, d, (int8_t *)(D + o_desc), (uint32_t *)(D + o_cbase), (int32_t *)(D + o_nrm),
                            (int32_t *)(D + o_cin), stats_dev, st);

@@ -366,9 +366,13 @@ class Stitcher:
         out[oy:oy + img_host.shape[0], ox:ox + img_host.shape[1]] = img_host
         return out
 
-    def _host_region(self, img, ox, oy, H, W, p1, p2):
+    def _host_region(self, img, ox, oy, H, W, p1, p2, stable=False):
         """get_roi_from_corners on the padded canvas of `img` (pasted at ox, oy) without building the
-        canvas: numpy slice semantics (clipped to the canvas), zeros outside the image."""
+        canvas: numpy slice semantics (clipped to the canvas), zeros outside the image.
+        A region downloaded from the device is a VIEW of the ctx's pinned staging block, valid until the next staging
+        call on the ctx (frame_download / frame_match / frame_transform); stable=True returns a private copy instead
+        (needed when another thread keeps reading it while this thread downloads the next region)."""
+        keep = (lambda v: np.array(v)) if stable else (lambda v: v)
         if isinstance(img, DeviceImage) and img._host is not None:
             img = img._host  # the frame came from the host: no download needed
         x0, y0 = max(0, min(W, p1[0])), max(0, min(H, p1[1]))
@@ -381,7 +385,7 @@ class Stitcher:
             if isinstance(img, DeviceImage) and self._seams_plain:
                 # one pitched DMA into the ctx's pinned block; the view is consumed by the detector right away
                 # (before the next staging call on the ctx)
-                return ops.frame_download(self._frame_ctx(), img.t[y0 - oy:y1 - oy, x0 - ox:x1 - ox])
+                return keep(ops.frame_download(self._frame_ctx(), img.t[y0 - oy:y1 - oy, x0 - ox:x1 - ox]))
             return np.asarray(img[y0 - oy:y1 - oy, x0 - ox:x1 - ox])
         ix0, iy0 = max(x0, ox), max(y0, oy)
         ix1, iy1 = min(x1, ox + img.shape[1]), min(y1, oy + img.shape[0])
@@ -389,7 +393,7 @@ class Stitcher:
         if isinstance(img, DeviceImage) and self._seams_plain and x1 > x0 and y1 > y0:
             # the slice reaches beyond the mosaic: zero frame + one pitched DMA of the part that exists, in the ctx
             src = img.t[iy0 - oy:iy1 - oy, ix0 - ox:ix1 - ox] if inter else img.t[0:0, 0:0]
-            return ops.frame_download(self._frame_ctx(), src, (y1 - y0, x1 - x0), (iy0 - y0, ix0 - x0) if inter else (0, 0))
+            return keep(ops.frame_download(self._frame_ctx(), src, (y1 - y0, x1 - x0), (iy0 - y0, ix0 - x0) if inter else (0, 0)))
         c = () if img.ndim == 2 else (img.shape[2],)
         out = np.zeros((y1 - y0, x1 - x0) + c, np.uint8)
         if inter:
@@ -629,7 +633,12 @@ class Stitcher:
                     else:
                         # a detector that works in HBM gets device views: the mosaic region never visits the host
                         region = self._device_region if dev_det else self._host_region
-                        cur_roi = region(img_d, ox, oy, H, W, current_corners[0], current_corners[1])
+                        # (parallel_detect: the frame's region is read by the worker thread while this thread downloads
+                        # the reference's region into the same pinned block -- it must be a private copy then)
+                        if dev_det:
+                            cur_roi = region(img_d, ox, oy, H, W, current_corners[0], current_corners[1])
+                        else:
+                            cur_roi = region(img_d, ox, oy, H, W, current_corners[0], current_corners[1], stable=self.parallel_detect)
                         (kps, thisdes), (rkps, refdes) = self._detect_two(
                             cur_roi, lambda: region(ref_d, rox, roy, H, W, corners[0], corners[1]))
                         if self._seams_plain:

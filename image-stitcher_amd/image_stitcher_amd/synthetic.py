@@ -163,3 +163,90 @@ def crop_path(world, n_frames, frame_hw=(480, 640), step_frac=0.15, max_rot_deg=
         if cx > W - fw * 0.75:
             break
     return frames, poses
+
+
+# ---------------------------------------------------------------------------------------------
+# the same kind of stream generated on the device (bench.py's long 1080p stream: a 4k x 10k world and 130 rotated
+# crops take minutes with scipy on the host, about a second here).  Another random stream than the numpy functions
+# above: whoever compares two paths feeds both the same frames.
+# ---------------------------------------------------------------------------------------------
+def procedural_world_torch(device, seed=42, h=3072, w=6144, speckle=0):
+    """procedural_world on `device`: multi-octave value noise + random rectangles (+ 3x3 high-contrast blobs, `speckle`
+    per 1000 pixels), uint8 (h, w, 3) tensor, every pixel >= 12."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    acc = torch.zeros((1, 3, h, w), dtype=torch.float32, device=device)
+    amp = 1.0
+    for cell in (256, 96, 32, 12, 5):
+        grid = torch.rand((1, 3, h // cell + 3, w // cell + 3), generator=g, device=device)
+        acc += amp * F.interpolate(grid, scale_factor=cell, mode="bilinear", align_corners=False)[..., :h, :w]
+        amp *= 0.62
+    acc = (acc - acc.min()) / (acc.max() - acc.min())
+    img = 30 + 200 * acc[0]
+    n = int(h * w / 40000)
+    ys = torch.randint(0, h - 8, (n,), generator=g, device=device).tolist()
+    xs = torch.randint(0, w - 8, (n,), generator=g, device=device).tolist()
+    sz = torch.randint(4, 60, (n, 2), generator=g, device=device).tolist()
+    col = torch.randint(12, 256, (n, 3), generator=g, device=device).to(torch.float32)
+    for k in range(n):
+        img[:, ys[k]:ys[k] + sz[k][0], xs[k]:xs[k] + sz[k][1]] = col[k][:, None, None]
+    if speckle:
+        m = int(h * w * speckle / 1000)
+        by = torch.randint(1, h - 2, (m,), generator=g, device=device)
+        bx = torch.randint(1, w - 2, (m,), generator=g, device=device)
+        dv = (torch.randint(0, 2, (m,), generator=g, device=device) * 2 - 1) * torch.randint(40, 100, (m,), generator=g, device=device)
+        delta = torch.zeros((1, 1, h, w), dtype=torch.float32, device=device)
+        delta[0, 0].index_put_((by, bx), dv.to(torch.float32), accumulate=True)
+        img = img + F.conv2d(delta, torch.ones((1, 1, 3, 3), device=device), padding=1)[0]
+    return img.clamp_(12, 255).to(torch.uint8).permute(1, 2, 0).contiguous()
+
+
+def serpentine_poses(n_frames, frame_hw=(1080, 1920), step_frac=0.15, per_row=28, down_steps=3, max_rot_deg=1.0, seed=43):
+    """Camera poses (cx, cy, theta) of a mapping flight: `per_row` frames to the right (step_frac of the frame width
+    each), `down_steps` frames downwards (step_frac of the frame HEIGHT... of the width, so that rows overlap by about
+    half a frame), then back to the left, and so on -- the mosaic grows in both axes.  Returns (poses, (h, w) of the
+    world that contains every frame)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    fh, fw = frame_hw
+    sx, sy = step_frac * fw, step_frac * fw * 0.6
+    margin = 0.75 * max(fw, fh)
+    cx, cy, direction = margin, margin, 1
+    poses, k = [], 0
+    while len(poses) < n_frames:
+        for _ in range(per_row):
+            poses.append((cx, cy, np.deg2rad(rng.uniform(-max_rot_deg, max_rot_deg))))
+            cx += direction * sx
+            cy += rng.uniform(-0.01, 0.01) * fh
+        cx -= direction * sx
+        for _ in range(down_steps):
+            cy += sy
+            poses.append((cx, cy, np.deg2rad(rng.uniform(-max_rot_deg, max_rot_deg))))
+        cy += sy
+        direction = -direction
+    poses = poses[:n_frames]
+    W = int(max(p[0] for p in poses) + margin) + 1
+    H = int(max(p[1] for p in poses) + margin) + 1
+    return poses, (H, W)
+
+
+def crop_poses_torch(world_t, poses, frame_hw=(1080, 1920)):
+    """Frames (uint8 numpy arrays, host) cut from a device world along `poses`: bilinear samples of the rotated frame
+    rectangle, as crop_path does with scipy."""
+    import torch
+    import torch.nn.functional as F
+    fh, fw = frame_hw
+    H, W = world_t.shape[:2]
+    dev = world_t.device
+    src = world_t.permute(2, 0, 1)[None].to(torch.float32)
+    ys, xs = torch.meshgrid(torch.arange(fh, device=dev, dtype=torch.float32) - (fh - 1) / 2,
+                            torch.arange(fw, device=dev, dtype=torch.float32) - (fw - 1) / 2, indexing="ij")
+    frames = []
+    for cx, cy, th in poses:
+        c, s = float(np.cos(th)), float(np.sin(th))
+        gx = (cx + c * xs - s * ys) * (2.0 / (W - 1)) - 1.0
+        gy = (cy + s * xs + c * ys) * (2.0 / (H - 1)) - 1.0
+        f = F.grid_sample(src, torch.stack([gx, gy], -1)[None], mode="bilinear", padding_mode="border", align_corners=True)
+        frames.append(f[0].round_().clamp_(12, 255).to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy())
+    return frames

@@ -276,3 +276,19 @@ def test_frame_match_train_segments_merge_exactly(cuda, orc, nq, nt, d):
     gq, gt = ops.frame_match(ctx, q.astype(np.float32), t.astype(np.float32), 0.8)
     oq, ot = orc.ratio_filter(*orc.knn2(q, t), 0.8)
     assert np.array_equal(gq, oq) and np.array_equal(gt, ot)
+    # norm="hamming" (cv2.BFMatcher(NORM_HAMMING)): the same segments, the XOR / popcount index kernel.  Hamming distances
+    # are small integers, so ties across segment boundaries are the rule here, in both slots
+    if d <= 64:
+        qb = rng.integers(0, 256, (nq, d), dtype=np.uint8)
+        tb = rng.integers(0, 256, (nt, d), dtype=np.uint8)
+        if nt > 400:
+            src = rng.permutation(nt)[:nq // 2]
+            qb[:len(src)] = tb[src] ^ (rng.random((len(src), d)) < 0.03).astype(np.uint8)
+            for a, b in [(3, 131), (10, 266), (127, 128), (40, nt - 1), (300, 301), (5, 389)]:
+                tb[b] = tb[a]
+            qb[-6:] = tb[[3, 10, 127, 40, 300, 5]]
+        for ratio in (0.65, 0.9, 1.0):
+            gq, gt = ops.frame_match(ctx, qb, tb, ratio, hamming=True)
+            ridx, rdist = orc.knn2(qb, tb, norm=orc.NORM_HAMMING)
+            oq, ot = orc.ratio_filter(ridx, rdist, ratio)
+            assert np.array_equal(gq, oq) and np.array_equal(gt, ot), ("hamming", ratio, len(gq), len(oq))

@@ -507,6 +507,41 @@ def test_parallel_detect_gives_the_same_stream(cuda, world, tmp_path, detector_a
 
 
 @pytest.mark.gpu
+def test_parallel_detect_with_device_frames_reads_a_private_region(cuda, world, tmp_path):
+    """Frames handed over as device tensors have no host copy, so the frame's detector region is downloaded into the
+    ctx's pinned staging block; with parallel_detect the worker thread reads it WHILE this thread downloads the
+    reference's region into the same block.  The frame's region must therefore be a private copy: a slow detector on the
+    worker thread makes the overlap certain, and the stream must equal the serial one."""
+    import time
+    import torch
+    from image_stitcher_amd import ConsecutiveStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    frames = _frames(world, 5)
+
+    class Slow(NumpyOrbLite):
+        def detectAndCompute(self, image, mask=None):
+            time.sleep(0.05)  # the main thread's download of the reference region lands in this window
+            return super().detectAndCompute(image, mask)
+
+    outs = {}
+    for par in (False, True):
+        det = (NumpyOrbLite(nfeatures=500), Slow(nfeatures=500)) if par else NumpyOrbLite(nfeatures=500)
+        st = ConsecutiveStitcher(log_level=0, output_dir=str(tmp_path / f"d{par}"), consecutive_range=2, algorithm=1,
+                                 detector=det, parallel_detect=par)
+        rec = []
+        for f in frames:
+            tf = st.stitch_consecutive(torch.from_numpy(f).cuda())
+            last = st.refs[-1]  # (the first frame is kept as handed over: a device tensor)
+            rec.append((last.cpu().numpy() if isinstance(last, torch.Tensor) else np.array(np.asarray(last)), st.corners,
+                        None if tf is None else np.array(tf.M)))
+        outs[par] = rec
+    assert outs[True][-1][2] is not None
+    for (m0, c0, t0), (m1, c1, t1) in zip(outs[False], outs[True]):
+        assert np.array_equal(m0, m1) and c0 == c1 and (t0 is None) == (t1 is None)
+        assert t0 is None or np.array_equal(t0, t1)
+
+
+@pytest.mark.gpu
 def test_arbitrary_stitcher_from_filepaths(cuda, world, tmp_path):
     """ArbitraryStitcher(filepaths=...) (stitcher.py:239-246): .png/.jpg paths are kept, others dropped, images
     are loaded lazily (cv2.imread, or PIL where cv2 is absent) and give the collections of the same arrays
