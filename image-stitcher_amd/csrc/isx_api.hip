@@ -13,7 +13,7 @@ int isx_fail(int status, const char *fmt, ...) {
     return status;
 }
 
-extern "C" int isx_version(void) { return 1; }
+extern "C" int isx_version(void) { return ISX_ABI_VERSION; }
 
 extern "C" const char *isx_last_error(void) { return g_err; }
 

@@ -54,6 +54,9 @@ SIGNATURES = {
     "isx_warp_alpha_blend": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64,
                                      c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_double,
                                      c_void_p, c_void_p]),
+    "isx_warp16": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
+                           c_int, c_int, c_void_p]),
+    "isx_alpha_blend16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_double, c_void_p]),
     "isx_alpha_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                 c_double, c_void_p]),
     "isx_gradient_blend": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p,
@@ -102,6 +105,7 @@ class NormLimitError(IsxError):
     so the integer ranking could differ from cv2's float ranking; the caller falls back to the fp32 matcher."""
 
 
+ABI_VERSION = 3  # include/isx.h ISX_ABI_VERSION
 _lib = None
 
 
@@ -120,6 +124,9 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        if L.isx_version() != ABI_VERSION:
+            raise IsxError(f"{LIB_PATH} was built for ABI version {L.isx_version()}, this package binds version {ABI_VERSION} "
+                           "(include/isx.h ISX_ABI_VERSION): rebuild with `python image-stitcher_amd/build.py --force`")
         _lib = L
     return _lib
 

@@ -127,3 +127,44 @@ class DeviceImage:
 
     def __repr__(self):
         return f"DeviceImage(shape={self.shape}, device={self.t.device})"
+
+
+class DepthImage:
+    """A single-channel uint16 image resident in HBM: what Stitcher(depth16=True) keeps as its mosaic (the opt-in
+    depth-preserving mode; the default wraps uint16 input modulo 256 as the reference's uint8 canvases do).  Array-like
+    enough for the stitchers and for user code that takes refs[-1]: shape, ndim, dtype, np.asarray()."""
+
+    def __init__(self, tensor):
+        if tensor.dtype != torch.uint16 or tensor.ndim != 2:
+            raise TypeError("DepthImage wraps a 2-D uint16 tensor")
+        self.t = tensor
+
+    @classmethod
+    def from_any(cls, img, device):
+        if isinstance(img, DepthImage):
+            return img
+        if isinstance(img, torch.Tensor):
+            return cls(img.to(device))
+        return cls(torch.from_numpy(np.ascontiguousarray(img)).to(device))
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+    @property
+    def ndim(self):
+        return 2
+
+    @property
+    def dtype(self):
+        return np.dtype(np.uint16)
+
+    def numpy(self):
+        return self.t.contiguous().cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __len__(self):
+        return self.t.shape[0]

@@ -570,6 +570,56 @@ def warp_alpha_blend(src, M, perspective, dst_rect, ref, contrib, src_xy=(0, 0),
     return out
 
 
+# ---- opt-in depth-preserving mode: single-channel uint16 images (BASELINE configs[3]; Stitcher(depth16=True)) ----
+def _img16_args(t, name="image"):
+    _require_cuda(t, name)
+    if t.dtype != torch.uint16 or t.ndim != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise IsxError(f"{name} must be a 2-D uint16 device tensor with contiguous rows")
+    return _ptr(t), int(t.shape[0]), int(t.shape[1]), int(t.stride(0)) * 2
+
+
+def warp16(src, M, perspective, dst_rect, src_xy=(0, 0)):
+    """warp() for a 2-D uint16 image (float32 linear arithmetic): canvas rectangle dst_rect = (x0, y0, w, h) as a new
+    (h, w) uint16 tensor."""
+    p, sh, sw, spitch = _img16_args(src, "src")
+    x0, y0, dw, dh = (int(v) for v in dst_rect)
+    M = np.ascontiguousarray(M, np.float64)
+    if M.shape != ((3, 3) if perspective else (2, 3)):
+        raise IsxError(f"M has shape {M.shape}")
+    with torch.cuda.device(src.device):
+        out = torch.empty((dh, dw), dtype=torch.uint16, device=src.device)
+        check(_lib.lib().isx_warp16(p, sh, sw, spitch, int(src_xy[0]), int(src_xy[1]), M.ctypes.data_as(ctypes.c_void_p),
+                                    _lib.MODEL_HOMOGRAPHY if perspective else _lib.MODEL_AFFINE_PARTIAL,
+                                    _ptr(out), 2 * dw, x0, y0, dw, dh, _stream()))
+    return out
+
+
+def alpha_blend16(warped, ref, contrib, out=None):
+    """seamless_merge(image1=warped, image2=ref, contrib) on 2-D uint16 images; out defaults to ref itself (in place)."""
+    pw, h, w, wp = _img16_args(warped, "warped")
+    pr, h2, w2, rp = _img16_args(ref, "ref")
+    if (h, w) != (h2, w2):
+        raise IsxError("warped and ref differ in shape")
+    out = ref if out is None else out
+    po, h3, w3, op = _img16_args(out, "out")
+    if (h3, w3) != (h, w):
+        raise IsxError("out differs in shape")
+    with torch.cuda.device(ref.device):
+        check(_lib.lib().isx_alpha_blend16(pw, wp, pr, rp, po, op, h, w, float(contrib), _stream()))
+    return out
+
+
+def bbox_nonzero16(img):
+    """get_corners_from_image of a 2-D uint16 device image: ((x0, y0), (x1, y1)) or False (synchronous).  A pixel is
+    non-zero iff one of its two bytes is: the uint8 reduction runs on the byte view and the columns are halved."""
+    if img.shape[0] == 0 or img.shape[1] == 0:
+        return False
+    bb = bbox_nonzero(img.view(torch.uint8)).cpu().numpy()
+    if not bb[4]:
+        return False
+    return ((int(bb[0]) >> 1, int(bb[1])), ((int(bb[2]) + 1) >> 1, int(bb[3])))
+
+
 def new_bbox(device):
     """A bbox accumulator (include/isx.h: ISX_BBOX_INTS int32 -- 5 result ints, then the caller-owned partial
     table the reduction kernels use), reset.  Read the result as acc[:5]."""

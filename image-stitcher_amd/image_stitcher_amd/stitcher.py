@@ -28,7 +28,7 @@ import torch
 from . import ops
 from .async_save import AsyncImageWriter, write_image
 from .detect import make_detector
-from .device_image import DeviceImage, MosaicArena
+from .device_image import DepthImage, DeviceImage, MosaicArena
 from .strips import StripMosaic
 from .pairs import components_from_counts, directed_items, gather_counts, pair_items, shard_pairs, unordered_pairs
 from .utils.logger import LogWrapper
@@ -129,7 +129,7 @@ class Stitcher:
                  blender=1,
                  ref_image_contrib=0.5,  # Used in alpha blending
                  *, detector=None, device=None, resident=True, norm="l2", async_save=False, warp_arith="f32",
-                 parallel_detect=False):
+                 parallel_detect=False, depth16=False):
         options = {
             "log_level": [logging.DEBUG, logging.INFO, logging.WARNING],
             "algorithm": ["sift", "orb", "akaze"],
@@ -184,6 +184,10 @@ class Stitcher:
         # (two cv2 objects are built), a pair `detector=(a, b)`, or one object that is safe to call from
         # two threads at once.
         self.parallel_detect = parallel_detect
+        # extension (opt-in): single-channel uint16 frames (depth maps) keep their 16 bits.  The reference allocates every
+        # canvas as uint8 (utils/proc.py:283-291), so a uint16 frame wraps modulo 256 there -- and here by default.  With
+        # depth16=True such frames take the warp / alpha-merge path of _stitch_depth16 below: the same steps on uint16.
+        self.depth16 = depth16
         self._own_detector = False
         self._detector_b = None
         if isinstance(detector, (tuple, list)):
@@ -583,10 +587,71 @@ class Stitcher:
         self.phase_seconds[name] = self.phase_seconds.get(name, 0.0) + (t1 - t0)
         return t1
 
+    @staticmethod
+    def _is_u16(a):
+        if isinstance(a, DepthImage):
+            return True
+        if isinstance(a, torch.Tensor):
+            return a.dtype == torch.uint16 and a.ndim == 2
+        return isinstance(a, np.ndarray) and a.dtype == np.uint16 and a.ndim == 2
+
+    def _stitch_depth16(self, arg_ref, arg_img, tf, corners):
+        """stitcher.py:176-229 for single-channel uint16 frames with the canvases in the FRAME's dtype (opt-in; the
+        reference's uint8 canvases wrap the values modulo 256, utils/proc.py:283-291): get_padded_images, warp_target
+        (INTER_LINEAR on CV_16U: float32 linear kernels), seamless_merge (blender=0) on uint16, corners of the warped
+        image, crop_image.  It is the warp/blend-only path of synchronised RGB + depth stitching (README.md:90-103):
+        the transform comes from the RGB stitcher (tf), a depth map is not something a feature detector is run on."""
+        if tf is None:
+            raise ops.IsxError("depth16=True stitches uint16 frames with a transform handed over (tf=...), as in the "
+                               "reference's synchronised RGB + depth use; detection on depth maps is not offered")
+        if self.blender != 0:
+            raise ops.IsxError("depth16=True needs blender=0 (alpha): the reference's gradient blender casts its result "
+                               "to uint8 (utils/proc.py:253)")
+        if self.warp_arith != "f32":
+            raise ops.IsxError("depth16=True runs the float32 linear warp only (warp_arith='f32')")
+        dev = self._dev()
+        img, ref = DepthImage.from_any(arg_img, dev), DepthImage.from_any(arg_ref, dev)
+        ih, iw = img.shape
+        rh, rw = ref.shape
+        W, H = rw + 2 * iw, rh + 2 * ih                      # utils/proc.py:295-304
+        ox, oy = (rw + iw) // 2, (rh + ih) // 2
+        M, src_pts, dst_pts = tf.get()
+        if M is None:
+            raise RuntimeError("transform estimation failed (cv2 would raise on M=None)")
+        M = np.asarray(M, np.float64)
+        with torch.cuda.device(dev):
+            canvas = torch.zeros((H, W), dtype=torch.uint16, device=dev)
+            canvas[ih:ih + rh, iw:iw + rw] = ref.t
+            qx0, qy0, qx1, qy1 = self._quad_region(M, ox, oy, iw, ih, W, H, 2)
+            wcorners = False
+            if qx1 > qx0 and qy1 > qy0:
+                # outside this rectangle the warped image is zero and the merge leaves the mosaic as it is
+                warped = ops.warp16(img.t, M, self.type == 1, (qx0, qy0, qx1 - qx0, qy1 - qy0), src_xy=(ox, oy))
+                if self.consecutive_range is not None:
+                    wc = ops.bbox_nonzero16(warped)
+                    if wc:
+                        wcorners = ((wc[0][0] + qx0, wc[0][1] + qy0), (wc[1][0] + qx0, wc[1][1] + qy0))
+                ops.alpha_blend16(warped, canvas[qy0:qy1, qx0:qx1], self.ref_image_contrib)
+            cc = ops.bbox_nonzero16(canvas)
+        if self.consecutive_range is not None:
+            corners = wcorners
+            if corners is False:
+                self.logger.warning("Could not get image corners. The merged image has no non-black regions.")
+                corners = None
+        if cc is False:
+            return None
+        (x0, y0), (x1, y1) = cc
+        mosaic = DepthImage(canvas[y0:y1, x0:x1])
+        if not self.resident:
+            mosaic = mosaic.numpy()
+        return mosaic, corners, tf
+
     @timer
     def stitch(self, arg_ref, arg_img, tf=None, corners=None):
         tp = time.perf_counter()
         dev = self._dev()
+        if self.depth16 and self._is_u16(arg_img) and self._is_u16(arg_ref):
+            return self._stitch_depth16(arg_ref, arg_img, tf, corners)
         img_d = DeviceImage.from_any(arg_img, dev)
         ref_d = arg_ref if isinstance(arg_ref, StripMosaic) else DeviceImage.from_any(arg_ref, dev)
         ih, iw = img_d.shape[:2]

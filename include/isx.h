@@ -15,8 +15,11 @@
  *     the call returns without synchronising unless stated otherwise;
  *   - every function returns 0 on success or a negative isx_status; isx_last_error() returns a
  *     thread-local human readable message for the last failure on the calling thread;
- *   - calls may be issued from any thread and on any stream; the library keeps no device state between
- *     calls;
+ *   - calls may be issued from any thread and on any stream.  Device state is held in exactly two places: an isx_ctx
+ *     (the per-stitcher workspace of the isx_frame_* calls: staging image, tables, pinned mirrors; created and
+ *     destroyed by the caller, not re-entrant within one ctx) and the 32 KiB file-scope table of
+ *     isx_bbox_nonzero_static (one per GPU, shared by every call on that GPU).  Every other entry point keeps no
+ *     state between calls;
  *   - there is no CPU fallback: without a HIP device the compute entry points fail with ISX_E_HIP.
  */
 #ifndef ISX_H
@@ -44,6 +47,12 @@ enum isx_model { ISX_MODEL_AFFINE_PARTIAL = 0, ISX_MODEL_HOMOGRAPHY = 1 }; /* st
 enum isx_warp_arith { ISX_WARP_LINEAR_F32 = 0, ISX_WARP_CLASSIC = 1 };
 enum isx_blender { ISX_BLEND_ALPHA = 0, ISX_BLEND_GRADIENT = 1 };          /* stitcher.py:153-156 `blender` */
 
+/* ABI version of this header.  isx_version() returns the value the library was built with; a caller compares the two
+ * before anything else (image_stitcher_amd._lib does).  History: 1 = round 1; 2 = round 2 (bbox_out_dev of isx_bbox_nonzero /
+ * isx_warp / isx_warp_arith / isx_warp_alpha_blend grew from int32[5] to int32[ISX_BBOX_INTS] under unchanged names: a
+ * round-1 caller passing 5 ints would be overwritten -- that is what this number is for); 3 = round 3 (additions only:
+ * isx_knn2_l2_count_pairs, isx_warp16, isx_alpha_blend16). */
+#define ISX_ABI_VERSION 3
 int isx_version(void);
 const char *isx_last_error(void);
 /* number of HIP devices visible (0 if none / no driver).  Never fails. */
@@ -224,6 +233,17 @@ int isx_warp(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int 
 int isx_warp_arith(const uint8_t *src_dev, int sh, int sw, int c, int64_t spitch, int src_x, int src_y,
                    const double *M_host, int model, uint8_t *dst_dev, int64_t dpitch, int dx0, int dy0, int dw,
                    int dh, int arith, int canvas_w, int canvas_h, int32_t *bbox_out_dev, void *stream);
+
+/* Opt-in depth-preserving mode (BASELINE configs[3]; Stitcher(depth16=True)).  The reference's canvases are uint8 whatever
+ * the frame's dtype (utils/proc.py:283-291), so uint16 depth wraps modulo 256 there -- the default here as well.  These two
+ * entry points are Stitcher.warp_target (stitcher.py:143-149) and seamless_merge (utils/proc.py:48-82) as the same code
+ * computes them when the canvases take the frame's dtype: single-channel uint16 images, pitches in BYTES (even).
+ * isx_warp16: arguments as isx_warp (float32 linear arithmetic only), dst = the rectangle's own buffer (dw x dh).
+ * isx_alpha_blend16: mask = v > 10, overlap products truncated in float64, uint16 sum wraps modulo 65536; out may alias ref. */
+int isx_warp16(const uint16_t *src_dev, int sh, int sw, int64_t spitch_bytes, int src_x, int src_y, const double *M_host,
+               int model, uint16_t *dst_dev, int64_t dpitch_bytes, int dx0, int dy0, int dw, int dh, void *stream);
+int isx_alpha_blend16(const uint16_t *warped_dev, int64_t wpitch_bytes, const uint16_t *ref_dev, int64_t rpitch_bytes,
+                      uint16_t *out_dev, int64_t opitch_bytes, int h, int w, double ref_contrib, void *stream);
 
 /* Replaces seamless_merge (utils/proc.py:48-82; Stitcher.merge blender=0, stitcher.py:153-154).
  * warped/ref/out are same-size views; out may alias ref. */

@@ -145,6 +145,25 @@ def alpha_blend(warped, ref, contrib):
     return out
 
 
+def warp16(src, M, dsize_wh, perspective):
+    """orc_warp16: the warp on a 2-D uint16 image (opt-in depth-preserving mode)."""
+    a = np.ascontiguousarray(src)
+    assert a.dtype == np.uint16 and a.ndim == 2
+    dw, dh = dsize_wh
+    M = np.ascontiguousarray(M, np.float64)
+    out = np.empty((dh, dw), np.uint16)
+    lib().orc_warp16(_p(a), a.shape[0], a.shape[1], _p(M), int(bool(perspective)), _p(out), dh, dw)
+    return out
+
+
+def alpha_blend16(warped, ref, contrib):
+    a, b = np.ascontiguousarray(warped), np.ascontiguousarray(ref)
+    assert a.dtype == b.dtype == np.uint16 and a.shape == b.shape and a.ndim == 2
+    out = np.empty_like(a)
+    lib().orc_alpha_blend16(_p(a), _p(b), a.shape[0], a.shape[1], ctypes.c_double(contrib), _p(out))
+    return out
+
+
 def gradient_blend(warped, ref, feather=10):
     """Returns the modified copy of ref (the reference mutates its argument)."""
     a, h, w, c = _img(warped)

@@ -185,6 +185,54 @@ void orc_warp(const uint8_t *src, int sh, int sw, int c, const double *M, int pe
         }
 }
 
+/* The same warp on a single-channel uint16 image (the opt-in depth-preserving mode: what stitcher.py:143-149 computes when
+ * the padded canvases take the frame's dtype instead of utils/proc.py:283's uint8).  [OCV-K] OpenCV 4.11's linear kernels serve
+ * CV_16U with the same float32 arithmetic; round half to even, saturate to 65535.  arith 0 only. */
+void orc_warp16(const uint16_t *src, int sh, int sw, const double *M, int perspective, uint16_t *dst, int dh, int dw) {
+    double iMd[9];
+    float m[9];
+    if (perspective) invert_3x3(M, iMd);
+    else { invert_affine(M, iMd); iMd[6] = 0; iMd[7] = 0; iMd[8] = 1; }
+    for (int i = 0; i < 9; i++) m[i] = (float)iMd[i];
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            float fx = (float)x, fy = (float)y;
+            float sx = fmaf(m[0], fx, fmaf(m[1], fy, m[2]));
+            float sy = fmaf(m[3], fx, fmaf(m[4], fy, m[5]));
+            if (perspective) {
+                float w = fmaf(m[6], fx, fmaf(m[7], fy, m[8]));
+                sx = sx / w;
+                sy = sy / w;
+            }
+            uint16_t *o = dst + (long)y * dw + x;
+            if (!(sx > -2.f && sx < (float)sw + 1.f && sy > -2.f && sy < (float)sh + 1.f)) { *o = 0; continue; }
+            float flx = floorf(sx), fly = floorf(sy);
+            int ix = (int)flx, iy = (int)fly;
+            float a = sx - flx, b = sy - fly;
+#define PX16(X, Y) (((unsigned)(X) >= (unsigned)sw || (unsigned)(Y) >= (unsigned)sh) ? 0.f : (float)src[(long)(Y) * sw + (X)])
+            float p00 = PX16(ix, iy), p01 = PX16(ix + 1, iy), p10 = PX16(ix, iy + 1), p11 = PX16(ix + 1, iy + 1);
+#undef PX16
+            float t0 = fmaf(a, p01 - p00, p00);
+            float t1 = fmaf(a, p11 - p10, p10);
+            float r = rintf(fmaf(b, t1 - t0, t0));
+            *o = (uint16_t)(r < 0.f ? 0 : (r > 65535.f ? 65535 : (int)r));
+        }
+}
+
+/* proc.py:48-82 seamless_merge on two 2-D uint16 arrays (same mode): :58-59 mask = v > 10 (cv2.threshold on the array itself),
+ * :70-71 float64 products stored into uint16 (truncation), :79 uint16 + uint16 wraps modulo 65536. */
+void orc_alpha_blend16(const uint16_t *warped, const uint16_t *ref, int h, int w, double contrib, uint16_t *out) {
+    const double one_minus = 1 - contrib;
+    for (long i = 0; i < (long)h * w; i++) {
+        uint16_t a = warped[i], b = ref[i];
+        if (a > 10 && b > 10) {
+            b = (uint16_t)(contrib * (double)b);
+            a = (uint16_t)(one_minus * (double)a);
+        }
+        out[i] = (uint16_t)(a + b);
+    }
+}
+
 /* ---- blenders ---------------------------------------------------------------------------------- */
 /* proc.py:48-82 seamless_merge(image1=warped, image2=ref, ref_image_contrib).
  *   :50-55 gray (3-D only)     :58-59 mask = gray > 10     :66 overlap = mask1 & mask2

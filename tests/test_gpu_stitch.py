@@ -86,6 +86,70 @@ def test_rgb_plus_depth_reusing_tf(cuda, orc, world, tmp_path):
         assert np.array_equal(np.asarray(dep.refs[-1]), o[0])
 
 
+def _oracle_depth16(orc, ref, img, M, contrib, persp):
+    """stitcher.py:176-229 on uint16 canvases (the opt-in depth-preserving mode): pad both, warp, alpha merge, corners of the
+    warped image, crop -- orc_warp16 / orc_alpha_blend16, bounding boxes by numpy."""
+    def bbox(a):
+        ys, xs = np.nonzero(a)
+        return False if len(ys) == 0 else ((int(xs.min()), int(ys.min())), (int(xs.max()) + 1, int(ys.max()) + 1))
+    ih, iw = img.shape
+    rh, rw = ref.shape
+    H, W = rh + 2 * ih, rw + 2 * iw
+    cur, refc = np.zeros((H, W), np.uint16), np.zeros((H, W), np.uint16)
+    cur[(H - ih) // 2:(H - ih) // 2 + ih, (W - iw) // 2:(W - iw) // 2 + iw] = img
+    refc[ih:ih + rh, iw:iw + rw] = ref
+    warped = orc.warp16(cur, M, (W, H), persp)
+    merged = orc.alpha_blend16(warped, refc, contrib)
+    (x0, y0), (x1, y1) = bbox(merged)
+    return merged[y0:y1, x0:x1], bbox(warped)
+
+
+@pytest.mark.parametrize("type_", [0, 1])
+def test_rgb_plus_depth16_keeps_sixteen_bits(cuda, orc, world, tmp_path, type_):
+    """BASELINE configs[3] in the opt-in depth-preserving mode (depth16=True): the depth stitcher reuses the RGB transform
+    (warp/blend-only path, blender=0, ref_image_contrib=0.5) and the uint16 mosaic keeps its 16 bits -- every frame
+    against the oracle's uint16 restatement of the same steps (warp in float32 linear arithmetic, round half to even;
+    v > 10 masks; truncated float64 products; uint16 sum).  Values above 255, above 32767 and a saturating 65535 patch are in
+    the frames; the default (depth16=False) wraps modulo 256 and is covered by test_rgb_plus_depth_reusing_tf."""
+    from image_stitcher_amd import ConsecutiveStitcher, TransformDetails
+    from image_stitcher_amd.detect import NumpyOrbLite
+    frames = _frames(world, 4)
+    rng = np.random.default_rng(0)
+    depth = []
+    for k, f in enumerate(frames):
+        d = (np.linspace(300, 60000, f.shape[1])[None, :] + 40 * k + rng.integers(0, 3, f.shape[:2])).astype(np.uint16)
+        d[5:25, 30:60] = 65535
+        d[40:60, 10:40] = rng.integers(0, 12, (20, 30))  # values around the mask threshold (10) and zeros
+        depth.append(d)
+    det = NumpyOrbLite(nfeatures=600)
+    kw = dict(log_level=3, output_dir=str(tmp_path), type=type_, blender=0, ref_image_contrib=0.5, consecutive_range=1)
+    rgb = ConsecutiveStitcher(algorithm=1, detector=det, **kw)
+    dep = ConsecutiveStitcher(algorithm=1, detector=det, depth16=True, **kw)
+    for k in range(len(frames)):
+        dref = None if dep.refs[-1] is None else np.array(np.asarray(dep.refs[-1]))
+        tf = rgb.stitch_consecutive(frames[k])
+        tf2 = dep.stitch_consecutive(depth[k], tf)
+        if k == 0:
+            assert tf is None and tf2 is None
+            continue
+        assert tf2 is tf and dref.dtype == np.uint16
+        want, wc = _oracle_depth16(orc, dref, depth[k], tf.M, 0.5, type_ == 1)
+        got = np.asarray(dep.refs[-1])
+        assert got.dtype == np.uint16 and got.shape == want.shape and np.array_equal(got, want), (got != want).sum()
+        assert dep.corners == wc
+    assert got.max() == 65535 and (got > 32767).any()
+    dep.save_last_stitch()  # blend_0.png, 16-bit
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(tmp_path / "blend_0.png")).astype(np.uint16), got)
+    # detection on depth maps is not offered, the gradient blender casts to uint8 in the reference: both refuse loudly
+    from image_stitcher_amd._lib import IsxError
+    with pytest.raises(IsxError):
+        dep.stitch(depth[0], depth[1])
+    with pytest.raises(IsxError):
+        ConsecutiveStitcher(log_level=3, output_dir=str(tmp_path), blender=1, depth16=True).stitch(
+            depth[0], depth[1], tf=TransformDetails(np.eye(2, 3), None, None))
+
+
 def test_failed_frame_resets_the_mosaic(cuda, world, tmp_path):
     """stitcher.py:425-433: a frame that cannot be matched saves blend_N.png, starts a new mosaic and is
     itself dropped; the caller's tf (None) comes back."""

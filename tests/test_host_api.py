@@ -29,7 +29,7 @@ def test_constructor_signatures_match_the_reference():
                                                   consecutive_volatility_threshold=4)
     # the build's extensions are keyword-only, so positional calls written for the reference keep their meaning
     kwonly = [k for k, p in inspect.signature(Stitcher.__init__).parameters.items() if p.kind is inspect.Parameter.KEYWORD_ONLY]
-    assert set(kwonly) == {"detector", "device", "resident", "norm", "async_save", "warp_arith", "parallel_detect"}
+    assert set(kwonly) == {"detector", "device", "resident", "norm", "async_save", "warp_arith", "parallel_detect", "depth16"}
 
 
 def test_initial_state_and_error_conventions(tmp_path):
