@@ -7,15 +7,19 @@ matcher and RANSAC are deterministic, so every rank derives the same transform M
 
 Per stitched frame
   * the region of the mosaic the detector needs (Stitcher.detectAndComputeFromCorners, stitcher.py:159-165) is
-    assembled from the strips that hold its rows: one all_gather of the row blocks (the "halo" of a strip boundary is
-    whatever part of the region lies on the other side of it);
-  * warp + blend: the warped frame, bbox(warped), the gradient blender's ROI (bbox +- 50 px, utils/proc.py:199-201)
-    and its row / column feather extents depend on the frame and M only, NOT on the mosaic, so every rank computes
-    them for the whole frame (isx_frame_blend's K1/K2, ~25 us) and blends only the rows of its own strip
-    (clip_rows).  No pixel crosses a strip boundary; a frame whose ROI straddles a boundary is simply blended by both
-    owners, each on its side;
-  * the merged canvas's bounding box (crop_image, stitcher.py:225) is the union of the strips' boxes: one small
-    all_reduce (min / max of 4 ints + 2 flags).
+    assembled from the strips that hold its rows: ONE all_gather_into_tensor of fixed-shape uint8 row blocks (every
+    rank derives every rank's rows from the bounds, so no header travels; RCCL on device tensors when the group is
+    nccl); the "halo" of a strip boundary is whatever part of the region lies on the other side of it;
+  * warp + blend is ROUTED: the warped frame, bbox(warped), the gradient blender's ROI (bbox +- 50 px,
+    utils/proc.py:199-201) and its row / column feather extents depend on the frame and M only, NOT on the mosaic, so
+    a rank whose rows meet the frame's rectangle Q (the warped quad +- 52 px) runs isx_frame_blend -- K1/K2 for the
+    whole frame, K3 on its own rows (clip_rows) -- and a rank whose rows do not meet it runs NOTHING: it takes the
+    warped image's bounding box from the owners in the reduction below.  No pixel crosses a strip boundary; a frame
+    whose ROI straddles a boundary is blended by both owners, each on its side;
+  * the merged canvas's bounding box (crop_image, stitcher.py:225), the owners' bbox(warped) and the slow-path flags
+    travel in ONE all_reduce(MAX) of 14 integers (a second one only on the rare rescan path);
+  * when the mosaic has grown so that one strip holds more than twice the mean number of rows, the bounds are re-split
+    evenly over the mosaic's rows and the rows that change owner move point to point (batch_isend_irecv).
 
 Coordinates: "world" = pixel coordinates fixed to the first reference image's top-left corner; rank r owns world rows
 [bounds[r], bounds[r+1]) (the first and last strip are open ended, so the mosaic may grow in every direction).
@@ -48,6 +52,9 @@ class StripMosaic:
         self.arena = None                   # MosaicArena of the local rows (None: this rank holds no row yet)
         self.ox = self.oy = 0               # world coordinates of arena.t[0, 0]
         self._host = None
+        self.bbox = False                   # bbox of the gray != 0 pixels of the whole mosaic, world coordinates (or False)
+        self.dirty = True                   # bytes of gray == 0 pixels may lie outside the crop
+        self._flags, self._wbox = (0, 0), False   # results of the last _union_over_ranks
 
     # ---- construction ---------------------------------------------------------------------------------
     @classmethod
@@ -115,18 +122,25 @@ class StripMosaic:
             st.frame_stats["arena_allocs"] += a.t is not t_before
 
     # ---- collectives ----------------------------------------------------------------------------------
-    def _union_over_ranks(self, box, flags=(0, 0)):
-        """box: (x0,y0,x1,y1) world or False -> union over the ranks (False if none); flags are OR-ed."""
+    def _union_over_ranks(self, box, flags=(0, 0), wbox=False):
+        """box: (x0,y0,x1,y1) world or False -> union over the ranks (False if none); flags are OR-ed; wbox (the warped
+        image's bounding box, known to the ranks that ran the frame kernels: False elsewhere) comes back in
+        self._wbox.  One all_reduce(MAX): minima travel negated."""
         dist = _dist()
-        lo = torch.tensor([box[0], box[1]] if box else [_INF, _INF], dtype=torch.int64)
-        hi = torch.tensor(([box[2], box[3]] if box else [-_INF, -_INF]) + [int(flags[0]), int(flags[1])], dtype=torch.int64)
+        v = [-_INF] * 10
+        if box:
+            v[0:4] = [-box[0], -box[1], box[2], box[3]]
+        v[4], v[5] = int(flags[0]), int(flags[1])
+        if wbox:
+            v[6:10] = [-wbox[0], -wbox[1], wbox[2], wbox[3]]
+        t = torch.tensor(v, dtype=torch.int64)
         if self._comm_on_device():
-            lo, hi = lo.to(self.device), hi.to(self.device)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
-        lo, hi = lo.cpu().tolist(), hi.cpu().tolist()
-        self._flags = (hi[2], hi[3])
-        return (lo[0], lo[1], hi[0], hi[1]) if hi[0] > lo[0] and hi[1] > lo[1] else False
+            t = t.to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        v = t.cpu().tolist()
+        self._flags = (max(0, v[4]), max(0, v[5]))
+        self._wbox = (-v[6], -v[7], v[8], v[9]) if v[8] > -v[6] and v[9] > -v[7] else False
+        return (-v[0], -v[1], v[2], v[3]) if v[2] > -v[0] and v[3] > -v[1] else False
 
     def _comm_on_device(self):
         dist = _dist()
@@ -157,26 +171,45 @@ class StripMosaic:
             bx0, by0, bx1, by1 = int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1
         return (bx0 + x0 + self.ox, by0 + y0 + self.oy, bx1 + x0 + self.ox, by1 + y0 + self.oy)
 
+    def _rows_of(self, r, bounds=None):
+        """World rows [y0, y1) of the mosaic held by rank r (every rank can tell: bounds and rectangle are common)."""
+        b = self.bounds if bounds is None else bounds
+        y0 = max(self.wy0, b[r])
+        return y0, max(y0, min(self.wy0 + self.h, b[r + 1]))
+
+    def _comm_device(self):
+        return self.device if self._comm_on_device() else torch.device("cpu")
+
     def region(self, x0, y0, x1, y1):
-        """Pixels [y0:y1, x0:x1] of the mosaic (mosaic coordinates, zeros outside it) as a numpy array on EVERY rank:
-        each rank contributes the rows it holds (one all_gather of the row blocks)."""
+        """Pixels [y0:y1, x0:x1] of the mosaic (mosaic coordinates, zeros outside it) as a numpy array on EVERY rank.
+        Each rank contributes the rows it holds as one fixed-shape uint8 block (padded to the tallest contribution;
+        which rows belong to whom follows from the bounds, so no header is exchanged): ONE all_gather_into_tensor --
+        RCCL on device tensors when the group is nccl, host tensors over gloo -- and one download of the result."""
         dist = _dist()
-        shape = (max(0, y1 - y0), max(0, x1 - x0)) + ((self.channels,) if self.ndim == 3 else ())
-        out = np.zeros(shape, np.uint8)
-        ly0, ly1 = self.local_rows()                                  # world rows held here
-        ry0, ry1 = max(y0 + self.wy0, ly0), min(y1 + self.wy0, ly1)    # world rows of the request held here
-        rx0, rx1 = max(x0, 0) + self.wx0, min(x1, self.w) + self.wx0
-        part = None
-        if self.arena is not None and ry1 > ry0 and rx1 > rx0:
-            v = self.arena.t[ry0 - self.oy:ry1 - self.oy, rx0 - self.ox:rx1 - self.ox]
-            part = (ry0 - self.wy0 - y0, rx0 - self.wx0 - x0, v.cpu().numpy())
-        parts = [None] * self.world
-        dist.all_gather_object(parts, part, group=self.group)
-        for p in parts:
-            if p is not None:
-                oy, ox, a = p
-                out[oy:oy + a.shape[0], ox:ox + a.shape[1]] = a
-        return out
+        tail = (self.channels,) if self.ndim == 3 else ()
+        shape = (max(0, y1 - y0), max(0, x1 - x0)) + tail
+        rx0, rx1 = max(x0, 0) + self.wx0, min(x1, self.w) + self.wx0          # world columns of the request inside the mosaic
+        spans = []
+        for r in range(self.world):
+            ly0, ly1 = self._rows_of(r)
+            ry0, ry1 = max(y0 + self.wy0, ly0), min(y1 + self.wy0, ly1)
+            spans.append((ry0, max(ry0, ry1)))
+        rows = max(b - a for a, b in spans)
+        if rows == 0 or rx1 <= rx0 or shape[0] == 0 or shape[1] == 0:
+            return np.zeros(shape, np.uint8)
+        cdev = self._comm_device()
+        block = torch.zeros((rows, rx1 - rx0) + tail, dtype=torch.uint8, device=cdev)
+        my0, my1 = spans[self.rank]
+        if self.arena is not None and my1 > my0:
+            block[:my1 - my0] = self.arena.t[my0 - self.oy:my1 - self.oy, rx0 - self.ox:rx1 - self.ox].to(cdev)
+        allb = torch.empty((self.world * rows,) + tuple(block.shape[1:]), dtype=torch.uint8, device=cdev)
+        dist.all_gather_into_tensor(allb, block, group=self.group)
+        out = torch.zeros(shape, dtype=torch.uint8, device=cdev)
+        cx = rx0 - self.wx0 - x0
+        for r, (a, b) in enumerate(spans):
+            if b > a:
+                out[a - self.wy0 - y0:b - self.wy0 - y0, cx:cx + (rx1 - rx0)] = allb[r * rows:r * rows + (b - a)]
+        return out.cpu().numpy()
 
     def numpy(self):
         if self._host is None:
@@ -211,11 +244,16 @@ class StripMosaic:
         arena_t = self.arena.t if self.arena is not None else torch.zeros((1, 1) + ((C,) if self.ndim == 3 else ()), dtype=torch.uint8, device=self.device)
         cax, cay = cwx - self.ox, cwy - self.oy                     # canvas -> arena
         ctx = st._frame_ctx()
-        res = ops.frame_blend(ctx, img_d.t, M, st.type == 1, (ox, oy), (W, H), arena_t, (cax, cay), (qx0, qy0, qw, qh),
-                              st.blender, st.ref_image_contrib, 10, st.warp_arith, clip_rows=(clip0, clip1))
+        if mine:
+            res = ops.frame_blend(ctx, img_d.t, M, st.type == 1, (ox, oy), (W, H), arena_t, (cax, cay), (qx0, qy0, qw, qh),
+                                  st.blender, st.ref_image_contrib, 10, st.warp_arith, clip_rows=(clip0, clip1))
+        else:
+            # routing: none of this rank's rows meets the frame's rectangle -- no kernel runs here; bbox(warped) comes
+            # from the owners with the reduction below
+            res = dict(wbbox=False, roi=None, mbbox=None, mfound=False, zeroed=False, dirty=False, done=True)
+            st.frame_stats["routed_away"] = st.frame_stats.get("routed_away", 0) + 1
         st.frame_stats["frames"] += 1
         wb = res["wbbox"]
-        wcorners = ((wb[0], wb[1]), (wb[2], wb[3])) if wb else False
         written = None
         rescan = False
         if st.blender == 0:
@@ -239,8 +277,13 @@ class StripMosaic:
         # local union rectangle (arena coordinates) of what can hold non-zero bytes now
         box = False
         flags = (int(bool(res["zeroed"]) or rescan), int(bool(res["dirty"]) or rescan or self.dirty))
-        self._union_over_ranks(False, flags)        # agree on the slow paths first
+        # ONE reduction: the slow-path flags, bbox(warped) from the owners, and the union of the boxes of the pixels written
+        # (valid unless some rank has to rescan)
+        mb = res["mbbox"]
+        box = (mb[0] + cwx, mb[1] + cwy, mb[2] + cwx, mb[3] + cwy) if res["mfound"] else False
+        new = self._union_over_ranks(box, flags, wb)
         g_rescan, g_dirty = self._flags
+        wcorners = ((self._wbox[0], self._wbox[1]), (self._wbox[2], self._wbox[3])) if self._wbox else False
         U = None
         if self.arena is not None:
             a = self.arena
@@ -252,13 +295,9 @@ class StripMosaic:
                 ux1, uy1 = max(ux1, written[2] + cax), max(uy1, written[3] + cay)
             if ux1 > ux0 and uy1 > uy0:
                 U = (ux0, uy0, ux1, uy1)
-        if g_rescan:
+        if g_rescan:  # (rare: uint8 wrap-around of the alpha blender, the rows-slow path) every rank rescans its rectangle
             st.frame_stats["rescans"] += 1
-            box = self._local_bbox_world(U) if U else False
-        else:
-            mb = res["mbbox"]
-            box = (mb[0] + cwx, mb[1] + cwy, mb[2] + cwx, mb[3] + cwy) if res["mfound"] else False
-        new = self._union_over_ranks(box)
+            new = self._union_over_ranks(self._local_bbox_world(U) if U else False)
         if not g_rescan and self.bbox:
             ob = self.bbox
             new = (min(ob[0], new[0]), min(ob[1], new[1]), max(ob[2], new[2]), max(ob[3], new[3])) if new else ob
@@ -270,7 +309,11 @@ class StripMosaic:
             # other strips may have widened the mosaic: keep its whole column range addressable over my rows
             ly0, ly1 = self.local_rows()
             if ly1 > ly0:
-                if U:   # arena coordinates shift when the arena is re-allocated
+                if U:
+                    # a re-allocation copies the arena's rectangle only: make it the union rectangle first, so that what this
+                    # frame wrote outside the old one travels too (the rectangle is set to the new mosaic's right below)
+                    self.arena.x, self.arena.y, self.arena.w, self.arena.h = U[0], U[1], U[2] - U[0], U[3] - U[1]
+                    # arena coordinates shift when the arena is re-allocated
                     U = (U[0] + self.ox, U[1] + self.oy, U[2] + self.ox, U[3] + self.oy)
                 self._ensure_cover(self.wx0, ly0, self.wx0 + self.w, ly1, iw, ih, st)
                 if U:
@@ -287,4 +330,68 @@ class StripMosaic:
                             a.t[y0:y1, x0:x1] = 0
                             st.frame_stats["clears"] += 1
         self.dirty = False
+        self._maybe_rebalance(iw, ih, st)
         return self, wcorners
+
+    # ---- re-splitting the bounds --------------------------------------------------------------------------
+    def _maybe_rebalance(self, iw, ih, st=None):
+        """The bounds were set by the first image's rows; a mosaic that grows downwards (or upwards) piles every new
+        row onto the last (first) strip.  When one strip holds more than twice the mean number of rows, or twice another strip's, the bounds are
+        re-split evenly over the mosaic's rows and the rows that change owner are sent point to point.  Every rank
+        takes the same decision from the same numbers (bounds and rectangle are common): nothing is exchanged to decide."""
+        if self.world == 1 or self.h < 4 * self.world:
+            return False
+        sizes = [b - a for a, b in (self._rows_of(r) for r in range(self.world))]
+        if max(sizes) * self.world <= 2 * self.h and max(sizes) <= 2 * min(sizes):
+            return False   # no strip above twice the mean, none above twice another
+        new_bounds = [-_INF] + [self.wy0 + (k * self.h) // self.world for k in range(1, self.world)] + [_INF]
+        self._move_rows(new_bounds, iw, ih)
+        if st is not None:
+            st.frame_stats["rebalances"] = st.frame_stats.get("rebalances", 0) + 1
+        return True
+
+    def _move_rows(self, new_bounds, pad_x, pad_y):
+        dist = _dist()
+        cdev = self._comm_device()
+        tail = (self.channels,) if self.ndim == 3 else ()
+        old = [self._rows_of(r) for r in range(self.world)]
+        new = [self._rows_of(r, new_bounds) for r in range(self.world)]
+        me = self.rank
+        peer = (lambda r: dist.get_global_rank(self.group, r)) if self.group is not None else (lambda r: r)
+
+        def cut(a, b):
+            y0, y1 = max(a[0], b[0]), min(a[1], b[1])
+            return (y0, y1) if y1 > y0 else None
+
+        def my_rows(y0, y1):
+            return self.arena.t[y0 - self.oy:y1 - self.oy, self.wx0 - self.ox:self.wx0 + self.w - self.ox]
+
+        p2p, incoming = [], []
+        for r in range(self.world):
+            if r == me:
+                continue
+            out_rows = cut(old[me], new[r])
+            if out_rows is not None:
+                p2p.append(dist.P2POp(dist.isend, my_rows(*out_rows).to(cdev).contiguous(), peer(r), self.group))
+            in_rows = cut(old[r], new[me])
+            if in_rows is not None:
+                buf = torch.empty((in_rows[1] - in_rows[0], self.w) + tail, dtype=torch.uint8, device=cdev)
+                p2p.append(dist.P2POp(dist.irecv, buf, peer(r), self.group))
+                incoming.append((in_rows, buf))
+        if p2p:
+            for req in dist.batch_isend_irecv(p2p):
+                req.wait()
+        ny0, ny1 = new[me]
+        if ny1 > ny0:
+            part = torch.zeros((ny1 - ny0, self.w) + tail, dtype=torch.uint8, device=self.device)
+            kept = cut(old[me], new[me])
+            if kept is not None:
+                part[kept[0] - ny0:kept[1] - ny0] = my_rows(*kept)
+            for (y0, y1), buf in incoming:
+                part[y0 - ny0:y1 - ny0] = buf.to(self.device)
+            self.arena = MosaicArena.around(part, int(pad_x), int(pad_y))
+            self.ox, self.oy = self.wx0 - self.arena.x, ny0 - self.arena.y
+        else:
+            self.arena = None
+        self.bounds = list(new_bounds)
+        self._sync_arena_rect()

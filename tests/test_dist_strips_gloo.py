@@ -45,11 +45,11 @@ def _canvas_M(place, ox, oy, cwx, cwy, iw, ih):
     return np.array([[c, -s, tx - c * cx + s * cy], [s, c, ty - s * cx - c * cy]], np.float64)
 
 
-def _oracle_chain(frames, blender, orc):
+def _oracle_chain(frames, blender, orc, placements=None):
     """The reference's loop on whole canvases; returns [(mosaic, world origin)] after each frame."""
     ref, wx, wy = frames[0], 0, 0
     states = []
-    for f, place in zip(frames[1:], PLACEMENTS):
+    for f, place in zip(frames[1:], PLACEMENTS if placements is None else placements):
         ih, iw = f.shape[:2]
         rh, rw = ref.shape[:2]
         cur_c, ref_c = orc.get_padded_images(f, ref)
@@ -116,7 +116,8 @@ def _install_oracle_frame_blend(ops, orc):
     ops.frame_blend = frame_blend
 
 
-def _worker(rank, world, port, blender, out_path):
+def _worker(rank, world, port, blender, out_path, placements=None):
+    placements = PLACEMENTS if placements is None else placements
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -127,13 +128,13 @@ def _worker(rank, world, port, blender, out_path):
         from image_stitcher_amd.strips import StripMosaic
         from oracle import orc
         _install_oracle_frame_blend(ops, orc)
-        frames = _frames(1 + len(PLACEMENTS), 48, 64, seed=11)
+        frames = _frames(1 + len(placements), 48, 64, seed=11)
         st = Stitcher(algorithm=0, blender=blender, device=torch.device("cpu"))
         st._ctx = object()                                          # the stand-in ignores the workspace handle
         m = StripMosaic.from_image(frames[0], dist.group.WORLD, "cpu")
         assert m.shape == frames[0].shape and np.array_equal(np.asarray(m), frames[0])
         snaps = []
-        for f, place in zip(frames[1:], PLACEMENTS):
+        for f, place in zip(frames[1:], placements):
             ih, iw = f.shape[:2]
             rh, rw = m.shape[:2]
             W, H = rw + 2 * iw, rh + 2 * ih
@@ -147,10 +148,11 @@ def _worker(rank, world, port, blender, out_path):
             full = np.asarray(m).copy()
             # a detector region straddling every strip boundary, partly outside the mosaic
             reg = m.region(-7, -5, m.w // 2 + 9, m.h + 6)
-            snaps.append((full, m.wx0, m.wy0, reg))
+            sizes = [b - a for a, b in (m._rows_of(r) for r in range(world))]
+            snaps.append((full, m.wx0, m.wy0, reg, sizes, dict(st.frame_stats)))
         if rank == 0:
             np.save(out_path, np.array(snaps, dtype=object), allow_pickle=True)
-            assert st.frame_stats["frames"] == len(PLACEMENTS)
+            assert st.frame_stats["frames"] == len(placements)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -164,7 +166,7 @@ def test_strips_concatenate_to_the_single_canvas_mosaic(tmp_path, orc, world, bl
     frames = _frames(1 + len(PLACEMENTS), 48, 64, seed=11)
     exp = _oracle_chain(frames, blender, orc)
     assert len(snaps) == len(exp)
-    for k, ((full, wx, wy, reg), (emos, ewx, ewy)) in enumerate(zip(snaps, exp)):
+    for k, ((full, wx, wy, reg, _sizes, _stats), (emos, ewx, ewy)) in enumerate(zip(snaps, exp)):
         assert (wx, wy) == (ewx, ewy), f"frame {k}: world origin {(wx, wy)} != {(ewx, ewy)}"
         assert full.shape == emos.shape and np.array_equal(full, emos), f"frame {k}: mosaic differs"
         h, w = emos.shape[:2]
@@ -181,3 +183,27 @@ def test_strip_bounds_split_the_first_image_evenly():
         assert len(b) == world + 1 and all(b[i] <= b[i + 1] for i in range(world))
         sizes = [min(h, b[r + 1]) - max(0, b[r]) for r in range(world)]
         assert sum(sizes) == h and max(sizes) - min(sizes) <= 1
+
+
+# the mosaic grows to 4x the first image's height, downwards only: without re-splitting every new row lands on the last rank
+DOWNWARD = [(6 * (k % 3) - 4, 20 * k, 0.03 * (-1) ** k) for k in range(1, 9)]
+
+
+@pytest.mark.parametrize("world,blender", [(2, 1), (3, 0), (4, 1)])
+def test_strips_rebalance_when_the_mosaic_grows_downward(tmp_path, orc, world, blender):
+    """A mosaic that grows 4x downward: the bounds are re-split (rows move point to point) so that no strip holds more
+    than twice the mean number of rows, frames that do not meet a rank's rows run no kernel there (routing), and after
+    every frame the strips still concatenate to the oracle's single-canvas mosaic, bit for bit."""
+    out = str(tmp_path / "snaps.npy")
+    mp.spawn(_worker, args=(world, _free_port(), blender, out, DOWNWARD), nprocs=world, join=True)
+    snaps = np.load(out, allow_pickle=True)  # written by this test itself
+    frames = _frames(1 + len(DOWNWARD), 48, 64, seed=11)
+    exp = _oracle_chain(frames, blender, orc, DOWNWARD)
+    for k, ((full, wx, wy, reg, sizes, stats), (emos, ewx, ewy)) in enumerate(zip(snaps, exp)):
+        assert (wx, wy) == (ewx, ewy) and full.shape == emos.shape and np.array_equal(full, emos), f"frame {k}"
+        assert sum(sizes) == emos.shape[0]
+        assert max(sizes) * world <= 2 * emos.shape[0] + world and max(sizes) <= 2 * min(sizes) + 2, (k, sizes)
+    assert snaps[-1][0].shape[0] >= 4 * 48 - 8
+    final_sizes, final_stats = snaps[-1][4], snaps[-1][5]
+    assert final_stats.get("rebalances", 0) >= 1 and min(final_sizes) > 0 and max(final_sizes) <= 2 * min(final_sizes) + 2
+    assert final_stats.get("routed_away", 0) >= 1, "rank 0 holds the top rows: late frames must not run kernels there"

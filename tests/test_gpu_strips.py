@@ -57,6 +57,10 @@ def test_two_ranks_hold_strips_that_concatenate_to_the_single_gpu_mosaic(cuda, o
         if name.startswith("march_down"):
             assert stats["rescans"] == 0 and stats["rows_slow"] == 0 and stats["arena_allocs"] <= 6
             assert per_frame[-1][0].shape[0] > 200 * 2.5
+            # the mosaic grew 2.5x downward and then up-left: the bounds were re-split on the way (rows moved between the
+            # two ranks), so no strip ends up more than twice as tall as the other
+            tall = [[b - a for a, b in sorted(s for s in owns if s is not None)] for _, _, owns in per_frame]
+            assert stats.get("rebalances", 0) >= 1 and all(len(t) == 2 and max(t) <= 2 * min(t) + 2 for t in tall[2:]), tall
     assert straddled >= 15, "the scenarios must really spread the mosaic over both ranks"
     # stitch_collections: same files as the single-GPU run
     images = collection_images()
