@@ -321,7 +321,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(ISX_K
         const int nv = min(4, max(0, P.dw - lx));
         uint32_t px[4];
         warp_quad<C, PERSP, CLASSIC>(src, P, P.dx0 + lx, P.dy0 + ly, nv, px);
-#ifndef ISX_DIAG_K1_NOSTORE
+#if defined(ISX_K3_REWARP)
+        // (A/B build, profiles/r03_image_kernels.md: K3 recomputes the warp of its own tile, nothing is staged)
+#elif !defined(ISX_DIAG_K1_NOSTORE)
         if (nv > 0) quad_store<C>(wbuf + (int64_t)ly * P.dpitch, lx, P.dw, px);
 #else
         if (px[0] + px[1] + px[2] + px[3] == 0x7FFFFFFFu) wbuf[0] = 1;
@@ -559,13 +561,22 @@ __global__ void __launch_bounds__(1024) frame_extent_kernel(const int32_t *__res
 // cols = {top[cstride], bottom[cstride]}.
 // ------------------------------------------------------------------------------------------------
 #define G3_IT 1
+#ifdef ISX_K3_REWARP
+#define ISX_K3_EXTRA , src_dev, P, (int)persp
+#else
+#define ISX_K3_EXTRA
+#endif
 template <int C>
 __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__restrict__ wbuf, int64_t wpitch,
                                                              uint8_t *mosaic_q, int64_t mpitch, int qx0, int qy0,
                                                              int qw, int qh, const int32_t *__restrict__ rows,
                                                              const int32_t *__restrict__ cols, int cstride, int nchunk,
                                                              int feather, int clip_y0, int clip_y1,
-                                                             const int32_t *__restrict__ res, int32_t *__restrict__ part) {
+                                                             const int32_t *__restrict__ res, int32_t *__restrict__ part
+#ifdef ISX_K3_REWARP
+                                                             , const uint8_t *__restrict__ src, const WarpParams P, int persp
+#endif
+                                                             ) {
     constexpr int NW = QuadRaw<C>::N;
     // per-workgroup partial {minx, miny, maxx, maxy, zeroed, dirty} (plain stores, folded on the host)
     // Tile of this workgroup.  Workgroup ids go round the 8 XCDs (id % 8): XCD x takes the x-th eighth of the tiles in
@@ -590,7 +601,19 @@ __global__ void __launch_bounds__(256) frame_gradient_kernel(const uint8_t *__re
         const int ly = lyb + 4 * it + lr, lyc = min(ly, qh - 1), Y = qy0 + ly;
         // (rows beyond Q and rows of another strip -- not addressable in this GPU's arena -- read as 0)
         const bool rd = lx < qw && ly < qh;
+#ifdef ISX_K3_REWARP
+        {
+            uint32_t px4[4];
+            const int nv = rd ? min(4, qw - lx) : 0;
+            if (persp)
+                warp_quad_f32<C, true>(src, P, qx0 + lx, Y, nv, px4);
+            else
+                warp_quad_f32<C, false>(src, P, qx0 + lx, Y, nv, px4);
+            raw_pack<C>(px4, dw[it]);
+        }
+#else
         raw_load<C>(wbuf + (int64_t)lyc * wpitch, lx, rd ? qw : 0, dw[it]);
+#endif
         raw_load<C>(mosaic_q + (int64_t)lyc * mpitch, lx, (rd && Y >= clip_y0 && Y < clip_y1) ? qw : 0, dr[it]);
 #ifdef ISX_DIAG_K3_NOFEATHER
         L[it] = INT_MAX, R[it] = -1;
@@ -966,10 +989,10 @@ extern "C" int isx_frame_blend(isx_ctx *ctx, const uint8_t *src_dev, int sh, int
                            canvas_h, 50, ctx->mask, nchunk, ctx->cols, cstride, ctx->out_dev);
         if (c == 3)
             hipLaunchKernelGGL((frame_gradient_kernel<3>), gb, dim3(256), 0, st, ctx->wbuf, wpitch, mosaic_q_dev, mpitch, q_x0,
-                               q_y0, q_w, q_h, ctx->rows, ctx->cols, cstride, nchunk, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
+                               q_y0, q_w, q_h, ctx->rows, ctx->cols, cstride, nchunk, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS ISX_K3_EXTRA);
         else
             hipLaunchKernelGGL((frame_gradient_kernel<1>), gb, dim3(256), 0, st, ctx->wbuf, wpitch, mosaic_q_dev, mpitch, q_x0,
-                               q_y0, q_w, q_h, ctx->rows, ctx->cols, cstride, nchunk, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS);
+                               q_y0, q_w, q_h, ctx->rows, ctx->cols, cstride, nchunk, feather, clip_y0, clip_y1, ctx->out_dev, ctx->out_dev + R_INTS ISX_K3_EXTRA);
         ctx->fold_n = n_part;
         ctx->pending = 1;
     } else {
