@@ -1,14 +1,15 @@
 // libisx_hip.so -- the one entry point that allocates nothing (static device scratch).
 #include "isx_common.h"
 // ------------------------------------------------------------------------------------------------
-// isx_bbox_nonzero_static: isx_bbox_nonzero for callers that cannot allocate (code under HIP graph capture,
-// tight serving loops): the per-block partial table lives in a library-owned static device array instead
+// isx_bbox_nonzero_static: isx_bbox_nonzero for callers that cannot allocate (tight serving loops, harnesses that
+// forbid hipMalloc; graph capture only after one eager warm-up call per device, see include/isx.h): the per-block
+// partial table lives in a library-owned static device array instead
 // of the tail of a caller-allocated accumulator, so the caller passes only its 5-int result.  No
 // counterpart in the reference.  The entry point calls no hipMalloc / hipFree / allocating routine.
 //   * the array is 32 KiB per GPU the library runs on, held until the process ends;
 //   * every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
-//     threads) race; the array keeps the last call's partials, which is harmless because a call only
-//     reads the entries [0, grid) its own kernel has just written;
+//     threads) race -- one stream per GPU; for SERIALISED calls the array keeping the last call's partials is
+//     harmless, because a call only reads the entries [0, grid) its own kernel has just written;
 //   * `scratch` below is a host-side stand-in for the symbol, NOT a device address: host code uses the
 //     per-device pointer obtained once with hipGetSymbolAddress, and the kernels take it as an argument.
 // ------------------------------------------------------------------------------------------------

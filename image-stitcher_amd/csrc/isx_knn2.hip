@@ -1322,12 +1322,18 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
 // three LDS-DMA buffers once per pass.
 // ------------------------------------------------------------------------------------------------
 #define ISX_PAIR_CAP 128
-#define ISX_PAIR_SPREAD 16384 /* norm spread of a class (128 query rows) beyond which it takes the per-value correction */
+#ifndef ISX_PAIR_SPREAD
+#define ISX_PAIR_SPREAD 16384
+#endif /* norm spread of a class (128 query rows) beyond which it takes the per-value correction */
 #ifndef ISX_PAIR_T
 #define ISX_PAIR_T 0 /* compile-time timing diagnostics (tools/build_variant.sh), results WRONG when != 0: 4 no exact recounts,
                         16 report the candidate counts, 32 exactly 16 recounts per direction, 64 no chunk barrier */
 #endif
 #define ISX_PAIR_MAX_ROWS 4096
+#ifndef ISX_PAIR_X
+#define ISX_PAIR_X 0 /* timing experiments on the step (WRONG results when != 0): 1 no sched_barrier per group, 2 no LDS atomics,
+                        4 no DPP lane reduction, 8 no row-direction maxima */
+#endif
 #define ISX_B3 (1 << 22) /* bias of the packed row-direction bound: keeps it positive */
 #define ISX_PAIR_LDS (3 * (128 * 128 + 128 * 4) + 256 + ISX_PAIR_MAX_ROWS * 16 + 64 * 4 + (4 + 2 * ISX_PAIR_CAP) * 4)
 
@@ -1415,6 +1421,10 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
 
     v4i qf[NCB][2];
     unsigned phantom = 0; // bit cb: this lane's column of block cb is beyond nq
+    // norms of this lane's 8 queries, for the pass that runs (na) and the one whose rows are already requested (na_nx):
+    // every global load of a pass is issued in one batch a pass ahead -- eight dependent loads in the column epilogue,
+    // and two more for the class's norm range, were 13 us of every pass (profiles/r03_knn2_count_pmc.md)
+    int na[NCB], na_nx[NCB];
     auto load_queries = [&](int pass) {
         const int q0 = pass * QPB + wave * QPW;
         phantom = 0;
@@ -1424,6 +1434,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             const v4i *p = (const v4i *)(desc + (int64_t)(it.q_start + (qi < nq ? qi : 0)) * DP);
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) qf[cb][ks] = (qi < nq) ? p[4 * ks + g] : v4i{0, 0, 0, 0};
+            na_nx[cb] = qi < nq ? nrm[it.q_start + qi] : -1;
             if (qi >= nq) phantom |= 1u << cb;
         }
     };
@@ -1442,15 +1453,18 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
         // the class's norm range (whatever the row order is: sortedness only makes it narrow)
         int kc = 0;
         unsigned dq[NCB]; // modes 1, 2: this lane's query of block cb has half norm floor(nmin / 2) + dq
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) na[cb] = na_nx[cb];
         if (wave_live) {
             int nmin = INT32_MAX, nmax = 0;
-            for (int qi = q0 + lane; qi < q0 + QPW && qi < nq; qi += 64) {
-                const int v = nrm[it.q_start + qi];
-                nmin = v < nmin ? v : nmin;
-                nmax = v > nmax ? v : nmax;
-            }
 #pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) {
+            for (int cb = 0; cb < NCB; cb++)
+                if (na[cb] >= 0) {
+                    nmin = na[cb] < nmin ? na[cb] : nmin;
+                    nmax = na[cb] > nmax ? na[cb] : nmax;
+                }
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) { // (the 16 columns; the four row groups g hold the same values)
                 const int a = __shfl_xor(nmin, sh), b = __shfl_xor(nmax, sh);
                 nmin = a < nmin ? a : nmin;
                 nmax = b > nmax ? b : nmax;
@@ -1467,7 +1481,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
                 const int qi = q0 + cb * 16 + col;
-                dq[cb] = (mode && qi < nq) ? (unsigned)((nrm[it.q_start + qi] >> 1) - (nmin >> 1)) : 0u;
+                dq[cb] = (mode && qi < nq) ? (unsigned)((na[cb] >> 1) - (nmin >> 1)) : 0u;
             }
         }
         unsigned m[NCB][2];
@@ -1498,16 +1512,19 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                     m[k][0] = umax3(m[k][0], (unsigned)P[k][0], (unsigned)P[k][2]);
                     m[k][1] = umax3(m[k][1], (unsigned)P[k][1], (unsigned)P[k][3]);
                     // row direction: max over the class's 8 column blocks, register r = k & 3
-                    if (k < 4)
+                    if (ISX_PAIR_X & 8) {
+                        if (k < 4) w[k] = 0;
+                    } else if (k < 4)
                         w[k] = umax3(x(0, k), x(1, k), x(2, k));
                     else
                         w[k - 4] = umax3(w[k - 4], x(3, k - 4), x(4, k - 4));
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(ISX_PAIR_X & 1)) __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     X[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[1], qf[k][1], X[k], 0, 0, 0);
-                    if (k < 2) {
+                    if (ISX_PAIR_X & 8) {
+                    } else if (k < 2) {
                         w[2 * k] = umax3(w[2 * k], x(5, 2 * k), x(6, 2 * k));
                         w[2 * k + 1] = umax3(w[2 * k + 1], x(5, 2 * k + 1), x(6, 2 * k + 1));
                     } else if (k < 4) {
@@ -1515,18 +1532,20 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                         const unsigned a7 = x(7, r), b7 = x(7, r + 1);
                         w[r] = w[r] > a7 ? w[r] : a7;
                         w[r + 1] = w[r + 1] > b7 ? w[r + 1] : b7;
-                    } else if (k == 4) { // 16 -> 4 lanes: two DPP maxima over the quads (the four chains interleave: no wait states)
+                    } else if (k == 4 && !(ISX_PAIR_X & 4)) { // 16 -> 4 lanes: two DPP maxima over the quads (the four chains interleave: no wait states)
                         asm volatile("v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                                      "v_max_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                                      "v_max_u32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                                      "v_max_u32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
                                      : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
-                    } else if (k == 5) {
+                    } else if (k == 5 && !(ISX_PAIR_X & 4)) {
                         asm volatile("v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                                      "v_max_u32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                                      "v_max_u32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                                      "v_max_u32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
                                      : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+                    } else if (k == 6 && (ISX_PAIR_X & 2)) {
+                        asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
                     } else if (k == 6) {
                         // the class's correction and tag, then the LDS max into the row table from the quad leaders only; the
                         // exec mask is switched by hand (a divergent `if` here splits the step into basic blocks and costs
@@ -1546,7 +1565,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                                        "n"(TB), "n"(TB + 16), "n"(TB + 32), "n"(TB + 48)
                                      : "memory");
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(ISX_PAIR_X & 1)) __builtin_amdgcn_sched_barrier(0);
                 }
             };
             v4i accA[NCB], accB[NCB];
@@ -1628,8 +1647,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 if (g == 0 && qi < nq && b1 != 0u) {
                     bool cand = true; // b2 == 0: fewer than two groups saw a train row -- let the exact scan decide
                     if (b2 != 0u && !(flags & 1)) {
-                        const int na = nrm[it.q_start + qi];
-                        const int s0_hi = na - 2 * ((int)b1 - ISX_B2), s1_hi = na - 2 * ((int)b2 - ISX_B2);
+                        const int s0_hi = na[cb] - 2 * ((int)b1 - ISX_B2), s1_hi = na[cb] - 2 * ((int)b2 - ISX_B2);
                         cand = ratio_good(s0_hi > 0 ? s0_hi - 1 : 0, s1_hi, ratio);
                     }
                     if (cand) {

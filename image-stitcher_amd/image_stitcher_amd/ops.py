@@ -120,7 +120,7 @@ def prepare_descriptor_tensor(src, starts, counts, check_range=True, wide_ok=Tru
 
 
 def sort_rows_by_norm(P):
-    """The same prepared set with the rows of every image sorted by norm (ascending).  For the count kernels only: the
+    """The same prepared set with the rows of every image sorted by norm (ascending, rotated by 64).  For the count kernels only: the
     number of good matches of an image pair does not depend on the row order, and isx_knn2_l2_count_pairs settles more
     queries without an exact recount when the 128 queries of a class have similar norms.  Needs images stored back to
     back (starts = cumsum(counts)), which is what prepare_descriptors produces; anything else is returned unchanged."""
@@ -137,10 +137,23 @@ def sort_rows_by_norm(P):
             img = torch.repeat_interleave(torch.arange(len(counts), device=dev, dtype=torch.int64),
                                           torch.from_numpy(counts).to(dev))
         perm = torch.argsort((img << 32) | P.nrm.to(torch.int64))
+        # The two tails of the sorted order are where a class of 128 rows spreads widely in norm (it then takes the kernel's
+        # slower per-value correction).  Rotating every image's order by 64 puts its 64 smallest norms behind its 64 largest:
+        # ONE wide class per image (the last) instead of two.
+        if len(set(counts.tolist())) == 1:
+            if int(counts[0]) > 256:
+                perm = perm.view(len(counts), int(counts[0])).roll(-64, dims=1).reshape(-1)
+        else:
+            cnt = torch.from_numpy(counts).to(dev)[img]
+            st = torch.from_numpy(starts).to(dev)[img]
+            pos = torch.arange(rows, device=dev, dtype=torch.int64) - st
+            src = st + torch.where(cnt > 256, (pos + 64) % cnt.clamp(min=1), pos)
+            perm = perm[src]
         return PreparedDescriptors(P.desc[perm], P.cbase[perm], P.nrm[perm], P.cin[perm], P.starts, P.counts, P.d, P.d_pad,
                                    P.max_norm2, P.wide)
 
 
+FRAME_MAX_Q = 32768    # include/isx.h ISX_FRAME_MAX_Q: largest side of the rectangle isx_frame_blend warps into
 PAIR_MAX_ROWS = 4096   # isx_knn2_l2_count_pairs: rows per image (its per-row table lives in LDS)
 PAIR_MIN_ITEMS = 2048  # below this many pairs the one-workgroup-per-pair kernel cannot fill the chip: use the directed kernel
 

@@ -503,6 +503,10 @@ class Stitcher:
         qw, qh = max(0, qx1 - qx0), max(0, qy1 - qy0)
         if qw == 0 or qh == 0:
             qx0 = qy0 = qw = qh = 0
+        if qw > ops.FRAME_MAX_Q or qh > ops.FRAME_MAX_Q:
+            # a degenerate transform (the quad's bound fell back to the whole canvas, or the frame is blown up beyond the
+            # frame pipeline's rectangle limit): the reference just produces a bad warp; so does the canvas path
+            return None, None
         cax, cay = arena.x - rox, arena.y - roy  # canvas -> arena
         if qw:
             t_before = arena.t
@@ -766,6 +770,8 @@ class Stitcher:
         else:
             with torch.cuda.device(dev):
                 mosaic, wcorners = self._blend_resident(img_d, ref_d, M, W, H, rox, roy, ox, oy)
+            if mosaic is None and wcorners is None:  # degenerate transform: materialised canvases, as the reference
+                return self._stitch_tail_via_seams(img_d, ref_d, M, tf)
         tp = self._phase("warp+blend", tp)
 
         if self.consecutive_range is not None:
@@ -947,6 +953,12 @@ class ArbitraryStitcher(Stitcher):
 
 
 class ConsecutiveStitcher(Stitcher):
+    """stitcher.py:377-439.  One difference a caller can see (resident=True, the default): `refs[-1]` is a DeviceImage
+    that ALIASES the stitcher's mosaic arena in HBM, and the next stitch_consecutive call blends into that arena in
+    place -- a mosaic kept from an earlier call (refs[-1], its `.t`, a cached host copy) changes or goes stale with it,
+    where the reference hands out a fresh ndarray per frame.  Take `np.array(np.asarray(st.refs[-1]))` (or construct
+    with resident=False: every result is then a private host array) to keep a frozen copy."""
+
     def __init__(self,
                  ref_image_contrib=0.2,
                  consecutive_range=1,

@@ -207,12 +207,16 @@ int isx_bbox_nonzero(const uint8_t *img_dev, int h, int w, int c, int64_t pitch,
 /* Re-initialise a bbox accumulator (for isx_warp's accumulating bbox output). */
 int isx_bbox_reset(int32_t *bbox_dev, void *stream);
 
-/* isx_bbox_nonzero for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  bbox_out_dev is just
- * the 5-int result {x0, y0, x1, y1, found}; the partial table is a static device array inside the library
- * (32 KiB per GPU, held until the process ends), so the entry point allocates nothing and needs no workspace.
- * Limits: h, w <= ISX_BBOX_STATIC_MAX_DIM (larger images are refused with ISX_E_ARG); the image's device
- * must be current and own `stream`; calls that overlap on one GPU race on the shared array. */
+/* isx_bbox_nonzero for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc, code that prepares a HIP graph).  NO COUNTERPART IN THE REFERENCE.  bbox_out_dev is just the 5-int result
+ * {x0, y0, x1, y1, found}; the partial table is a static device array inside the library (32 KiB per GPU, held until
+ * the process ends), so the entry point allocates nothing and needs no workspace.
+ * Limits: h, w <= ISX_BBOX_STATIC_MAX_DIM (larger images are refused with ISX_E_ARG); the image's device must be
+ * current and own `stream`.  ONE STREAM PER GPU: every call on a GPU uses that GPU's one table, so two calls that can
+ * overlap on a GPU (two streams, two threads) race and return garbage boxes; serialise them or use isx_bbox_nonzero.
+ * The first call on a device resolves the table's address (hipGetSymbolAddress, under a mutex) and every call queries
+ * the current device and the stream's device: make one eager call per device BEFORE a stream capture begins -- a first
+ * call issued during capture may be refused by the runtime.  Capturing later calls is untested here. */
 #define ISX_BBOX_STATIC_MAX_DIM 65536
 int isx_bbox_nonzero_static(const uint8_t *img_dev, int h, int w, int c, int64_t pitch, int32_t *bbox_out_dev,
                             void *stream);

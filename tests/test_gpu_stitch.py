@@ -606,6 +606,28 @@ def test_parallel_detect_with_device_frames_reads_a_private_region(cuda, world, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("blender", [0, 1])
+def test_rectangle_beyond_the_frame_pipeline_limit_takes_the_canvas_path(cuda, orc, world, tmp_path, blender, monkeypatch):
+    """A transform whose warped quad exceeds ISX_FRAME_MAX_Q (a degenerate homography: the quad's bound falls back to the
+    whole canvas) must not raise from the frame pipeline: the stitch falls back to materialised canvases, as the
+    reference computes it.  The limit is lowered for the test; the mosaic must equal the oracle's."""
+    from image_stitcher_amd import Stitcher, TransformDetails, ops
+    frames = _frames(world, 2)
+    ih, iw = frames[1].shape[:2]
+    rh, rw = frames[0].shape[:2]
+    ox, oy = (rw + iw) // 2, (rh + ih) // 2
+    M = np.array([[1.0, 0.0, iw + 40.0 - ox], [0.0, 1.0, ih + 12.0 - oy]])
+    pts = np.zeros((5, 1, 2), np.float32)
+    monkeypatch.setattr(ops, "FRAME_MAX_Q", 64)
+    st = Stitcher(log_level=3, output_dir=str(tmp_path), type=0, blender=blender, ref_image_contrib=0.5, consecutive_range=1,
+                  detector=object())
+    got = st.stitch(frames[0], frames[1], tf=TransformDetails(M, pts, pts))
+    o = oracle_stitch(frames[0], frames[1], None, Cfg(type=0, blender=blender, ref_image_contrib=0.5, consecutive_range=1),
+                      tf=(M, pts, pts))
+    assert np.array_equal(np.asarray(got[0]), o[0]) and got[1] == o[1]
+
+
+@pytest.mark.gpu
 def test_arbitrary_stitcher_from_filepaths(cuda, world, tmp_path):
     """ArbitraryStitcher(filepaths=...) (stitcher.py:239-246): .png/.jpg paths are kept, others dropped, images
     are loaded lazily (cv2.imread, or PIL where cv2 is absent) and give the collections of the same arrays
