@@ -1332,7 +1332,7 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
 #define ISX_PAIR_MAX_ROWS 4096
 #ifndef ISX_PAIR_X
 #define ISX_PAIR_X 0 /* timing experiments on the step (WRONG results when != 0): 1 no sched_barrier per group, 2 no LDS atomics,
-                        4 no DPP lane reduction, 8 no row-direction maxima */
+                        4 no DPP lane reduction, 8 no row-direction maxima, 16 the waves' LDS atomics land on different rows */
 #endif
 #define ISX_B3 (1 << 22) /* bias of the packed row-direction bound: keeps it positive */
 #define ISX_PAIR_LDS (3 * (128 * 128 + 128 * 4) + 256 + ISX_PAIR_MAX_ROWS * 16 + 64 * 4 + (4 + 2 * ISX_PAIR_CAP) * 4)
@@ -1578,7 +1578,8 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
                 if (c + 2 < n_chunks) stage_chunk(c + 2, buf2);
                 const unsigned char *base = smem + buf * BUF;
-                const unsigned slot_addr = row_slot_lds + c * (CHUNK * 16);
+                const unsigned slot_addr = (ISX_PAIR_X & 16) ? row_slot_lds + ((c * (CHUNK * 16) + wave * 8192) & 0xFFFF & ~2047)  // (diag: every wave its own rows)
+                                                             : row_slot_lds + c * (CHUNK * 16);
                 if (wave_live) {
                     auto two_tiles = [&](auto tc) {
                         constexpr int t = decltype(tc)::value;
