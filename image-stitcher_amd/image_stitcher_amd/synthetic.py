@@ -199,7 +199,8 @@ def procedural_world_torch(device, seed=42, h=3072, w=6144, speckle=0):
         dv = (torch.randint(0, 2, (m,), generator=g, device=device) * 2 - 1) * torch.randint(40, 100, (m,), generator=g, device=device)
         delta = torch.zeros((1, 1, h, w), dtype=torch.float32, device=device)
         delta[0, 0].index_put_((by, bx), dv.to(torch.float32), accumulate=True)
-        img = img + F.conv2d(delta, torch.ones((1, 1, 3, 3), device=device), padding=1)[0]
+        # 3x3 box sum (avg_pool: a plain kernel -- conv2d would send MIOpen on a multi-second search for an algorithm)
+        img = img + 9.0 * F.avg_pool2d(delta, 3, stride=1, padding=1, count_include_pad=True)[0]
     return img.clamp_(12, 255).to(torch.uint8).permute(1, 2, 0).contiguous()
 
 
