@@ -1319,7 +1319,7 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
 // needed.  Rows sorted by norm inside an image (ops.prepare_descriptor_tensor(sort_rows=True); counts do not depend on the
 // row order) make that spread small; unsorted input is still exact, only more candidates pass.
 // One workgroup (8 waves, 2 per SIMD) per pair, the query image in 4 passes of 1024; the train image streams through the
-// three LDS-DMA buffers once per pass.
+// four LDS-DMA buffers once per pass.
 // ------------------------------------------------------------------------------------------------
 #define ISX_PAIR_CAP 128
 #ifndef ISX_PAIR_SPREAD
@@ -1332,10 +1332,12 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
 #define ISX_PAIR_MAX_ROWS 4096
 #ifndef ISX_PAIR_X
 #define ISX_PAIR_X 0 /* timing experiments on the step (WRONG results when != 0): 1 no sched_barrier per group, 2 no LDS atomics,
-                        4 no DPP lane reduction, 8 no row-direction maxima, 16 the waves' LDS atomics land on different rows */
+                        4 no DPP lane reduction, 8 no row-direction maxima, 16 the waves' LDS atomics land on different rows,
+                        32 no LDS fragment reads */
 #endif
 #define ISX_B3 (1 << 22) /* bias of the packed row-direction bound: keeps it positive */
-#define ISX_PAIR_LDS (3 * (128 * 128 + 128 * 4) + 256 + ISX_PAIR_MAX_ROWS * 16 + 64 * 4 + (4 + 2 * ISX_PAIR_CAP) * 4)
+#define ISX_PAIR_NBUF 4 /* staging buffers: the chunk being read, the next one (its first tile is read a step early), two in flight */
+#define ISX_PAIR_LDS (ISX_PAIR_NBUF * (128 * 128 + 128 * 4) + 256 + ISX_PAIR_MAX_ROWS * 16 + 64 * 4 + (4 + 2 * ISX_PAIR_CAP) * 4)
 
 __device__ __forceinline__ unsigned dpp_quad_max(unsigned v) { // maximum over each group of 4 lanes, in every lane
     unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); // quad_perm [1,0,3,2]
@@ -1354,8 +1356,9 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
     constexpr int QPW = 16 * NCB, QPB = WAVES * QPW;
     extern __shared__ __align__(16) unsigned char smem[];
     // (one dummy tile in front: the software pipeline's first fold runs on an all-zero accumulator of "tile -1")
-    unsigned *rowtab = (unsigned *)(smem + 3 * BUF + 256);           // [ISX_PAIR_MAX_ROWS][4]: packed (bound << 5 | class)
-    int *cls = (int *)(smem + 3 * BUF + 256 + ISX_PAIR_MAX_ROWS * 16);     // [32][2]: bound offset, 2 floor(nmin/2) - nmax
+    constexpr int NBUF = ISX_PAIR_NBUF;
+    unsigned *rowtab = (unsigned *)(smem + NBUF * BUF + 256);           // [ISX_PAIR_MAX_ROWS][4]: packed (bound << 5 | class)
+    int *cls = (int *)(smem + NBUF * BUF + 256 + ISX_PAIR_MAX_ROWS * 16);     // [32][2]: bound offset, 2 floor(nmin/2) - nmax
     int *lst = cls + 64;                                             // n_col, n_row, good_col, good_row, col list, row list
 
     const int item_i = blockIdx.x;
@@ -1398,6 +1401,11 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                                                  lane * 4, c * (CHUNK * 4) + (wv & 1) * 256, 0, 0);
     };
     static_assert(PIECES % WAVES == 0 && PPW + 1 == 3, "the counted waits below assume 3 DMA instructions per wave and stage");
+    auto stage_first = [&]() { // the chunks a pass starts on
+#pragma unroll
+        for (int c = 0; c < NBUF - 1; c++)
+            if (c < n_chunks) stage_chunk(c, c);
+    };
 #pragma clang diagnostic pop
     struct Frag {
         v4i a[2];
@@ -1411,13 +1419,17 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
     const unsigned foc = CHUNK * DP + 16 * g;
     auto read_frag = [&](const unsigned char *base, auto tc, Frag &f) {
         constexpr int t = decltype(tc)::value;
+        if (ISX_PAIR_X & 32) { // (timing diagnostic: no fragment reads)
+            asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.cv));
+            return;
+        }
         f.a[0] = *(const v4i *)(base + fo0 + t * (16 * DP));
         f.a[1] = *(const v4i *)(base + fo1 + t * (16 * DP));
         f.cv = *(const v4i *)(base + foc + t * 64);
     };
-    // this lane's slot of the row table for register 0 of tile 0 of chunk 0 (quad leaders write): row 4g, group (lane>>2)&3
+    // this lane's slot of the row table in tile 0 of chunk 0: row 4g + (lane & 3), group (lane >> 2) & 3
     // as an LDS byte address, one tile back (the dummy tile): the fold adds (tile + 1) * 256 + 16 r as an immediate
-    const unsigned row_slot_lds = smem_lds + 3 * BUF + ((4 * g) * 4 + ((lane >> 2) & 3)) * 4;
+    const unsigned row_slot_lds = smem_lds + NBUF * BUF + ((4 * g + (lane & 3)) * 4 + ((lane >> 2) & 3)) * 4;
 
     v4i qf[NCB][2];
     unsigned phantom = 0; // bit cb: this lane's column of block cb is beyond nq
@@ -1438,9 +1450,11 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             if (qi >= nq) phantom |= 1u << cb;
         }
     };
+#ifdef ISX_PAIR_PRIO /* experiment: static priority for the second-dispatched half of the waves */
+    if (wave >= WAVES / 2) __builtin_amdgcn_s_setprio(ISX_PAIR_PRIO);
+#endif
     load_queries(0);
-    if (n_chunks > 0) stage_chunk(0, 0);
-    if (n_chunks > 1) stage_chunk(1, 1);
+    stage_first();
 
     for (int pass = 0; pass < n_pass; pass++) {
         const int q0 = pass * QPB + wave * QPW;
@@ -1532,37 +1546,34 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                         const unsigned a7 = x(7, r), b7 = x(7, r + 1);
                         w[r] = w[r] > a7 ? w[r] : a7;
                         w[r + 1] = w[r + 1] > b7 ? w[r + 1] : b7;
-                    } else if (k == 4 && !(ISX_PAIR_X & 4)) { // 16 -> 4 lanes: two DPP maxima over the quads (the four chains interleave: no wait states)
+                    } else if (k == 4 && !(ISX_PAIR_X & 4)) {
+                        // 16 -> 4 lanes AND 4 registers -> 1: after the two quad steps lane j of a quad holds row register j's
+                        // maximum over the quad (a butterfly: pair maxima, select by lane bit 0, pair maxima, select by lane
+                        // bit 1) -- 9 vector ops, and then ONE tag op and ONE ds_max_u32 from all 64 lanes instead of four
+                        // of each from the quad leaders
                         asm volatile("v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                                      "v_max_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                                      "v_max_u32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                     "v_max_u32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-                                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+                                     "v_max_u32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_cndmask_b32_e64 %0, %0, %1, %4\n\t"
+                                     "v_cndmask_b32_e64 %2, %2, %3, %4"
+                                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])
+                                     : "s"(0xAAAAAAAAAAAAAAAAull));
                     } else if (k == 5 && !(ISX_PAIR_X & 4)) {
                         asm volatile("v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
                                      "v_max_u32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                                     "v_max_u32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                                     "v_max_u32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+                                     "v_cndmask_b32_e64 %0, %0, %1, %2"
+                                     : "+v"(w[0]), "+v"(w[2])
+                                     : "s"(0xCCCCCCCCCCCCCCCCull));
                     } else if (k == 6 && (ISX_PAIR_X & 2)) {
                         asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
                     } else if (k == 6) {
-                        // the class's correction and tag, then the LDS max into the row table from the quad leaders only; the
-                        // exec mask is switched by hand (a divergent `if` here splits the step into basic blocks and costs
-                        // 60 VGPRs of spills)
-                        unsigned long long keep;
-                        asm volatile("v_lshl_add_u32 %1, %1, 5, %6\n\t"
-                                     "v_lshl_add_u32 %2, %2, 5, %6\n\t"
-                                     "v_lshl_add_u32 %3, %3, 5, %6\n\t"
-                                     "v_lshl_add_u32 %4, %4, 5, %6\n\t"
-                                     "s_mov_b64 %0, exec\n\t"
-                                     "s_mov_b64 exec, %7\n\t"
-                                     "ds_max_u32 %5, %1 offset:%8\n\tds_max_u32 %5, %2 offset:%9\n\t"
-                                     "ds_max_u32 %5, %3 offset:%10\n\tds_max_u32 %5, %4 offset:%11\n\t"
-                                     "s_mov_b64 exec, %0"
-                                     : "=&s"(keep), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])
-                                     : "v"(slot_addr), "s"(kcl), "s"(0x1111111111111111ull),
-                                       "n"(TB), "n"(TB + 16), "n"(TB + 32), "n"(TB + 48)
+                        // the class's correction and tag, then the LDS max into the row table: lane -> (row 4g + (lane & 3),
+                        // group (lane >> 2) & 3), 64 consecutive words per tile
+                        asm volatile("v_lshl_add_u32 %0, %0, 5, %2\n\t"
+                                     "ds_max_u32 %1, %0 offset:%3"
+                                     : "+v"(w[0])
+                                     : "v"(slot_addr), "s"(kcl), "n"(TB)
                                      : "memory");
                     }
                     if (!(ISX_PAIR_X & 1)) __builtin_amdgcn_sched_barrier(0);
@@ -1571,12 +1582,12 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             v4i accA[NCB], accB[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) accB[cb] = v4i{0, 0, 0, 0};
-            Frag f0, f1;
+            Frag f0{}, f1{};
             if (wave_live) read_frag(smem, std::integral_constant<int, 0>{}, f0);
             int buf = 0;
             for (int c = 0; c < n_chunks; c++) {
-                const int buf1 = buf == 2 ? 0 : buf + 1, buf2 = buf1 == 2 ? 0 : buf1 + 1;
-                if (c + 2 < n_chunks) stage_chunk(c + 2, buf2);
+                const int buf1 = (buf + 1) & (NBUF - 1);
+                if (c + NBUF - 1 < n_chunks) stage_chunk(c + NBUF - 1, (buf + NBUF - 1) & (NBUF - 1));
                 const unsigned char *base = smem + buf * BUF;
                 const unsigned slot_addr = (ISX_PAIR_X & 16) ? row_slot_lds + ((c * (CHUNK * 16) + wave * 8192) & 0xFFFF & ~2047)  // (diag: every wave its own rows)
                                                              : row_slot_lds + c * (CHUNK * 16);
@@ -1596,13 +1607,14 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                     two_tiles(std::integral_constant<int, 4>{});
                     two_tiles(std::integral_constant<int, 6>{});
                 }
-                // chunk c + 1 must have landed and every wave must be done with chunk c.  A __syncthreads() here waits for
-                // ALL memory operations (vmcnt(0)), i.e. also for chunk c + 2, issued a moment ago; wait for all but the
-                // newest stage instead.  The LDS reads of chunk c were consumed by this iteration's matrix instructions,
-                // the table atomics are only read after the last pass.
+                // Chunks up to c + 2 must have landed and every wave must be done with chunk c: the next iteration reads
+                // chunk c + 1 and, one step early, the first tile of chunk c + 2.  A __syncthreads() here waits for ALL
+                // memory operations (vmcnt(0)), i.e. also for chunk c + 3, issued a moment ago; wait for all but the
+                // newest stage instead (chunk c + 2 has been travelling for two iterations).  The LDS reads of chunk c
+                // were consumed by this iteration's matrix instructions, the table atomics are only read after the last pass.
                 if (ISX_PAIR_T & 64)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (timing diagnostic: no chunk barrier)
-                else if (c + 2 < n_chunks)
+                else if (c + NBUF - 1 < n_chunks)
                     asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1616,7 +1628,14 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 step(f0, accA, accB, row_slot_lds + (n_chunks - 1) * (CHUNK * 16), std::integral_constant<int, 7>{});
         };
 
-        __syncthreads(); // the first two chunks of this pass have landed (staged before the previous pass's epilogue)
+        __syncthreads(); // the first three chunks of this pass have landed (staged before the previous pass's epilogue)
+#ifdef ISX_PAIR_REP /* timing diagnostic: the chunk loop of every pass ISX_PAIR_REP times (maxima are idempotent: same results) */
+        for (int rep = 1; rep < ISX_PAIR_REP; rep++) {
+            run_chunks(std::integral_constant<int, 0>{});
+            stage_first();
+            __syncthreads();
+        }
+#endif
         if (mode == 0)
             run_chunks(std::integral_constant<int, 0>{});
         else if (mode == 1)
@@ -1626,8 +1645,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
         // every wave is past the last chunk's barrier: the buffers are free.  Start the next pass's first chunks and query
         // rows now, so that they travel while this pass's column results are evaluated.
         if (pass + 1 < n_pass) {
-            if (n_chunks > 0) stage_chunk(0, 0);
-            if (n_chunks > 1) stage_chunk(1, 1);
+            stage_first();
             load_queries(pass + 1);
         }
 

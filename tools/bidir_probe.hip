@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(256, 3) probe(int iters, unsigned *out) {
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+static int g_wps = 3; // workgroups per CU = waves per SIMD (argv[1]; 3 as knn2_count16_kernel, 2 as knn2_pair_filter_kernel)
 template <int MODE> static double run(int iters, unsigned *out, int blocks) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, iters / 10, out);
@@ -171,11 +172,14 @@ template <int MODE> static double run(int iters, unsigned *out, int blocks) {
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     // 3 workgroups of 4 waves per CU: 3 waves per SIMD run concurrently; units per SIMD = 3 waves x iters x 2
-    return ms * 1e6 / ((double)iters * 2 * 3);
+    return ms * 1e6 / ((double)iters * 2 * g_wps);
 }
 
-int main() {
-    const int blocks = 256 * 3; // every CU holds 3 workgroups (one wave of each per SIMD)
+int main(int argc, char **argv) {
+    if (argc > 1) g_wps = atoi(argv[1]);
+    if (g_wps < 1 || g_wps > 3) { printf("waves per SIMD: 1..3\n"); return 1; }
+    const int blocks = 256 * g_wps; // every CU holds g_wps workgroups (one wave of each per SIMD)
+    printf("%d waves per SIMD\n", g_wps);
     unsigned *out; CK(hipMalloc(&out, blocks * 256 * 4));
     const int iters = 20000;
     const double a = run<0>(iters, out, blocks), b = run<1>(iters, out, blocks), c = run<2>(iters, out, blocks);
