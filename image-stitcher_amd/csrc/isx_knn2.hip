@@ -1333,7 +1333,8 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
 #ifndef ISX_PAIR_X
 #define ISX_PAIR_X 0 /* timing experiments on the step (WRONG results when != 0): 1 no sched_barrier per group, 2 no LDS atomics,
                         4 no DPP lane reduction, 8 no row-direction maxima, 16 the waves' LDS atomics land on different rows,
-                        32 no LDS fragment reads */
+                        32 no LDS fragment reads, 64 no column epilogue (the compiler then drops the column folds of the loop as well:
+                        this measures both), 128 the first pass's query rows in every pass */
 #endif
 #define ISX_B3 (1 << 22) /* bias of the packed row-direction bound: keeps it positive */
 #define ISX_PAIR_NBUF 4 /* staging buffers: the chunk being read, the next one (its first tile is read a step early), two in flight */
@@ -1345,6 +1346,45 @@ __device__ __forceinline__ unsigned dpp_quad_max(unsigned v) { // maximum over e
     o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);          // quad_perm [2,3,0,1]
     return v > o ? v : o;
 }
+
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+// minimum / maximum over each row of 16 lanes, in every lane of the row (quad_perm, quad_perm, row_half_mirror, row_mirror)
+__device__ __forceinline__ int row16_min(int v) {
+    int o = dpp_i32<0xB1>(v); v = o < v ? o : v;
+    o = dpp_i32<0x4E>(v); v = o < v ? o : v;
+    o = dpp_i32<0x141>(v); v = o < v ? o : v;
+    o = dpp_i32<0x140>(v); return o < v ? o : v;
+}
+__device__ __forceinline__ int row16_max(int v) {
+    int o = dpp_i32<0xB1>(v); v = o > v ? o : v;
+    o = dpp_i32<0x4E>(v); v = o > v ? o : v;
+    o = dpp_i32<0x141>(v); v = o > v ? o : v;
+    o = dpp_i32<0x140>(v); return o > v ? o : v;
+}
+// (largest, second largest) of the values the four lanes {l, l ^ 16, l ^ 32, l ^ 48} hold as (b1 >= b2) pairs, in each of them:
+// two v_permlane*_swap exchanges instead of four LDS-crossbar shuffles
+__device__ __forceinline__ void top2_over_rows(unsigned &b1, unsigned &b2) {
+    {
+        const auto p = __builtin_amdgcn_permlane16_swap(b1, b1, false, false); // {own, partner} in some order
+        const auto q = __builtin_amdgcn_permlane16_swap(b2, b2, false, false);
+        const unsigned mn = p[0] < p[1] ? p[0] : p[1], mx2 = q[0] > q[1] ? q[0] : q[1];
+        b1 = p[0] > p[1] ? p[0] : p[1];
+        b2 = mn > mx2 ? mn : mx2;
+    }
+    {
+        const auto p = __builtin_amdgcn_permlane32_swap(b1, b1, false, false);
+        const auto q = __builtin_amdgcn_permlane32_swap(b2, b2, false, false);
+        const unsigned mn = p[0] < p[1] ? p[0] : p[1], mx2 = q[0] > q[1] ? q[0] : q[1];
+        b1 = p[0] > p[1] ? p[0] : p[1];
+        b2 = mn > mx2 ? mn : mx2;
+    }
+}
+// A float that is certainly above ratio^2: (float)s0 > (float)s1 * ratio2_up(ratio) implies !ratio_good(s0, s1, ratio) --
+// sqrtf, the two int -> float conversions and the float product are each off by at most 2^-24 relatively, the double product
+// by 2^-53; 2^-19 covers them with room.  (A NaN ratio compares false: the exact test decides.)
+__device__ __forceinline__ float ratio2_up(double ratio) { return __double2float_ru(ratio * ratio * (1.0 + 0x1p-19)); }
 
 template <int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
@@ -1369,6 +1409,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
     const int nt = it.nt, nq = it.nq;
     const int n_chunks = (nt + CHUNK - 1) / CHUNK;
     const int n_pass = (nq + QPB - 1) / QPB;
+    const float r2_up = ratio2_up(ratio);
 
     for (int i = tid; i < n_chunks * CHUNK; i += 64 * WAVES) ((uint4 *)rowtab)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid < 4) lst[tid] = 0;
@@ -1477,12 +1518,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                     nmin = na[cb] < nmin ? na[cb] : nmin;
                     nmax = na[cb] > nmax ? na[cb] : nmax;
                 }
-#pragma unroll
-            for (int sh = 1; sh < 16; sh <<= 1) { // (the 16 columns; the four row groups g hold the same values)
-                const int a = __shfl_xor(nmin, sh), b = __shfl_xor(nmax, sh);
-                nmin = a < nmin ? a : nmin;
-                nmax = b > nmax ? b : nmax;
-            }
+            nmin = row16_min(nmin), nmax = row16_max(nmax); // (the 16 columns; the four row groups g hold the same values)
             const int off = ISX_B3 - (nmin >> 1);
             kc = __builtin_amdgcn_readfirstlane((off << 5) | cls_id);
             // a class whose norms spread widely (the two tails of a sorted image, every class of an unsorted one) would
@@ -1646,32 +1682,39 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
         // rows now, so that they travel while this pass's column results are evaluated.
         if (pass + 1 < n_pass) {
             stage_first();
-            load_queries(pass + 1);
+            if (!(ISX_PAIR_X & 128)) load_queries(pass + 1);
         }
 
-        // column direction of this pass: candidates among this wave's 128 queries
-        if (wave_live) {
+        // column direction of this pass: candidates among this wave's 128 queries.  Almost no query is one: every lane
+        // first takes the cheap conservative reject (one float product), and only a wave that has a survivor enters the
+        // exact test (two IEEE sqrtf each); the four row groups are merged with v_permlane*_swap instead of 32
+        // LDS-crossbar shuffles: -1 % of the kernel (profiles/r03_knn2_count_pmc.md)
+        if (wave_live && !(ISX_PAIR_X & 64)) {
+            unsigned maybe = 0;
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
                 unsigned b1 = m[cb][0] > m[cb][1] ? m[cb][0] : m[cb][1];
                 unsigned b2 = m[cb][0] > m[cb][1] ? m[cb][1] : m[cb][0];
-#pragma unroll
-                for (int sh = 16; sh <= 32; sh <<= 1) {
-                    const unsigned o1 = __shfl_xor(b1, sh), o2 = __shfl_xor(b2, sh);
-                    const unsigned mn = b1 > o1 ? o1 : b1, mx2 = b2 > o2 ? b2 : o2;
-                    b1 = b1 > o1 ? b1 : o1;
-                    b2 = mn > mx2 ? mn : mx2;
-                }
-                const int qi = q0 + cb * 16 + col;
-                if (g == 0 && qi < nq && b1 != 0u) {
-                    bool cand = true; // b2 == 0: fewer than two groups saw a train row -- let the exact scan decide
+                top2_over_rows(b1, b2);
+                m[cb][0] = b1, m[cb][1] = b2;
+                const int s0_hi = na[cb] - 2 * ((int)b1 - ISX_B2), s1_hi = na[cb] - 2 * ((int)b2 - ISX_B2);
+                // b2 == 0: fewer than two groups saw a train row -- let the exact scan decide
+                const bool rejected = b2 != 0u && !(flags & 1) && (float)(s0_hi > 0 ? s0_hi - 1 : 0) > (float)s1_hi * r2_up;
+                if (b1 != 0u && na[cb] >= 0 && !rejected) maybe |= 1u << cb;
+            }
+            if (g != 0) maybe = 0;
+            if (__builtin_amdgcn_ballot_w64(maybe != 0u) != 0ull) {
+                for (int cb = 0; cb < NCB; cb++) {
+                    if (!(maybe & (1u << cb))) continue;
+                    const unsigned b1 = m[cb][0], b2 = m[cb][1];
+                    bool cand = true;
                     if (b2 != 0u && !(flags & 1)) {
                         const int s0_hi = na[cb] - 2 * ((int)b1 - ISX_B2), s1_hi = na[cb] - 2 * ((int)b2 - ISX_B2);
                         cand = ratio_good(s0_hi > 0 ? s0_hi - 1 : 0, s1_hi, ratio);
                     }
                     if (cand) {
                         const int pos = atomicAdd(&lst[0], 1);
-                        if (pos < ISX_PAIR_CAP) lst[4 + pos] = qi;
+                        if (pos < ISX_PAIR_CAP) lst[4 + pos] = q0 + cb * 16 + col;
                     }
                 }
             }
