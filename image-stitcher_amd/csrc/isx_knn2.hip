@@ -1665,6 +1665,13 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
         };
 
         __syncthreads(); // the first three chunks of this pass have landed (staged before the previous pass's epilogue)
+        // Overlapping images: once the column direction has overflowed its candidate list the pair goes to the two-pass
+        // kernel anyway -- leave now (both directions reported as -1) instead of forming the remaining products.  The
+        // barrier above has drained this wave's DMA; lst[0] only changes in the column epilogue, before that barrier.
+        if (pass > 0 && lst[0] > ISX_PAIR_CAP && !(ISX_PAIR_T & 20)) {
+            if (tid == 0) count_out[2 * (int64_t)item_i] = count_out[2 * (int64_t)item_i + 1] = -1;
+            return;
+        }
 #ifdef ISX_PAIR_REP /* timing diagnostic: the chunk loop of every pass ISX_PAIR_REP times (maxima are idempotent: same results) */
         for (int rep = 1; rep < ISX_PAIR_REP; rep++) {
             run_chunks(std::integral_constant<int, 0>{});

@@ -125,8 +125,9 @@ int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, cons
  * {t_start, nt} = image i.
  *   count_out_dev[2 e]     = len(good_matches) of (query = image j, train = image i)
  *   count_out_dev[2 e + 1] = len(good_matches) of (query = image i, train = image j)
- *   -1 = that direction has more than 128 candidates (the images overlap): the caller runs it as an item of
- *        isx_knn2_l2_count_items.  Every other value is the exact count (same as isx_knn2_l2_count_items).
+ *   -1 = that direction has more than 128 candidates (the images overlap), or the other direction of the pair had and
+ *        the kernel left the pair early: the caller runs it as an item of isx_knn2_l2_count_items.  Every other value
+ *        is the exact count (same as isx_knn2_l2_count_items).
  * count_out_dev need not be zeroed.  d_pad must be 128 and max_rows (max over items of nq and nt) <= 4096.  Rows sorted
  * by nrm inside each image keep the candidate lists short (counts do not depend on the row order); any order is exact.
  * flags bit 0 = test hook: every query is a candidate. */
