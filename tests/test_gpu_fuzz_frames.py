@@ -33,3 +33,13 @@ def test_fuzz_count_kernels_against_the_oracle(cuda, orc):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import fuzz_count
     assert fuzz_count.main(25) == 0
+
+
+def test_fuzz_pair_kernel_against_the_oracle(cuda, orc):
+    """tools/fuzz_pairs.py: isx_knn2_l2_count_pairs (one distance matrix per unordered pair: filter, exact recount, overflow to
+    the directed kernel, early exit) against the oracle on ragged 128-d image sets of up to 4096 rows, sorted and unsorted,
+    with planted near-duplicates from a handful to most of an image (250 cases ran clean on the round's final kernel; a short
+    campaign on other seeds here)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz_pairs
+    assert fuzz_pairs.main(20, 180000) == 0
