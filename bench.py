@@ -7,8 +7,8 @@
 Workload (BASELINE.json configs[2], the configuration the metric "image pairs matched/sec (SIFT 4k kp)"
 is quoted on; it fits one GPU): ArbitraryStitcher.get_collections over 512 shuffled crops x 4096
 SIFT-like keypoints (integer-valued 128-d descriptors, 8 planted scenes of 64 overlapping images,
-SURVEY.md section 8d).  One STEP = one full all-pairs pass: [all_gather of the per-rank descriptor
-shards over RCCL when N>1] -> descriptor preparation (+ rows sorted by norm) -> fused kNN-2 + Lowe-ratio
+SURVEY.md section 8d).  One STEP = one full all-pairs pass: descriptor preparation (+ rows sorted by norm) of the
+rank's own images -> [all_gather of the prepared rows over RCCL when N>1] -> fused kNN-2 + Lowe-ratio
 counts of both directions of this rank's share of the 130,816 unordered pairs (one launch over all pairs,
 one over the overlapping ones) -> gather of the int32 good-match counts -> host union-find on rank 0.  Inputs (the raw uint8 descriptor shard) are resident in HBM
 when the timed region starts.  The pair space is fixed and split over the ranks => "scaling":
@@ -338,21 +338,28 @@ def main():
     plan = ops.plan_items(prs.directed_items(my_pairs, starts, counts) if two_pass else prs.pair_items(my_pairs, starts, counts), dev)
     stage = {}
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]  # step start | after all_gather | after kernel | after gather
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]  # step start | after all_gather | after kernel | after gather | [4] after local prep
     kernel_ms, parts = [], []
     result = {}
 
     def step(record):
         if record:
             marks[0].record()
-        full = prs.all_gather_descriptors(local) if world > 1 else local
+        # every rank prepares (and, for the pair kernel, sorts by norm) the rows of ITS images only, and the prepared rows
+        # travel: the all_gather moves 9 % more bytes than raw descriptors would, and no rank repeats another's preparation
+        # (round 2 gathered the raw bytes and prepared all n images on every rank: ~1.2 ms of every step, whatever N)
+        Pl = ops.prepare_descriptor_tensor(local.reshape(-1, d), starts[:per], counts[:per])
+        if not two_pass:
+            Pl = ops.sort_rows_by_norm(Pl)
+        if record:
+            marks[4].record()
+        P = prs.all_gather_prepared(Pl, starts, counts) if world > 1 else Pl
         if record:
             marks[1].record()
-        P = ops.prepare_descriptor_tensor(full.reshape(-1, d), starts, counts)
         if two_pass:
             c = ops.knn2_l2_items(P, None, ratio, plan=plan, events=ev if record else None)
         else:
-            c = ops.knn2_l2_pairs(ops.sort_rows_by_norm(P), None, ratio, plan=plan, events=ev if record else None, stats=stage)
+            c = ops.knn2_l2_pairs(P, None, ratio, plan=plan, events=ev if record else None, stats=stage)
         if record:
             marks[2].record()
         allc = prs.gather_counts(c.view(-1, 2), len(all_pairs), rank, world)
@@ -368,10 +375,11 @@ def main():
             torch.cuda.synchronize()
             host_ms = (time.perf_counter() - t_host) * 1e3
             kernel_ms.append(ev[0].elapsed_time(ev[1]))
-            # per-phase GPU time of this rank's step: all_gather | desc_prep + count kernel | gather; host = counts
+            # per-phase GPU time of this rank's step: all_gather of the prepared rows | desc_prep + sort of the rank's own
+            # images + count kernels | gather; host = counts
             # read-back + union-find (rank 0)
-            parts.append((marks[0].elapsed_time(marks[1]), marks[1].elapsed_time(marks[2]), marks[2].elapsed_time(marks[3]),
-                          host_ms))
+            parts.append((marks[4].elapsed_time(marks[1]), marks[0].elapsed_time(marks[4]) + marks[1].elapsed_time(marks[2]),
+                          marks[2].elapsed_time(marks[3]), host_ms))
 
     def fence():
         torch.cuda.synchronize()

@@ -85,6 +85,29 @@ def all_gather_descriptors(local_des, group=None, always=False):
     return out
 
 
+def all_gather_prepared(Pl, starts, counts, group=None, always=False):
+    """Every rank has prepared (ops.prepare_descriptor_tensor, optionally ops.sort_rows_by_norm) the rows of ITS images --
+    equal row counts on every rank, images in rank order; returns the PreparedDescriptors of all images.  ONE all_gather of
+    one uint8 buffer per rank ([desc | cbase | nrm | cin] as bytes: uint8 is the element type every backend carries, and a
+    step keeps a single collective on the way in), then one copy per field to make the fields contiguous again."""
+    from . import ops
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1 and not always:
+        return ops.PreparedDescriptors(Pl.desc, Pl.cbase, Pl.nrm, Pl.cin, starts, counts, Pl.d, Pl.d_pad, Pl.max_norm2, Pl.wide)
+    rows = Pl.desc.shape[0]
+    parts = [Pl.desc.contiguous().view(torch.uint8).reshape(-1)] + \
+            [t.contiguous().view(torch.uint8).reshape(-1) for t in (Pl.cbase, Pl.nrm, Pl.cin)]
+    sizes = [int(t.numel()) for t in parts]
+    buf = torch.cat(parts)
+    out = all_gather_descriptors(buf.view(1, -1), group=group, always=always)   # (world, bytes per rank)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    field = lambda k: out[:, int(offs[k]):int(offs[k + 1])].contiguous().view(-1)
+    desc = field(0).view(torch.int8).view(world * rows, Pl.d_pad)
+    cbase, nrm, cin = (field(k).view(torch.int32) for k in (1, 2, 3))
+    return ops.PreparedDescriptors(desc, cbase, nrm, cin, starts, counts, Pl.d, Pl.d_pad, Pl.max_norm2, Pl.wide)
+
+
 def gather_counts(local_counts, n_pairs_total, rank, world, group=None, always=False):
     """local_counts: (p_local, 2) int32 for pairs rank::world.  Rank 0 returns (n_pairs_total, 2); others None."""
     import torch.distributed as dist

@@ -1,6 +1,6 @@
 """The collectives of the sharded get_collections path issued through RCCL (backend "nccl") on device tensors
 of the shapes and dtypes bench.py uses, in a process group of one rank: checks that RCCL accepts the calls
-(uint8 all_gather_into_tensor with a concatenated output, int32 gather to rank 0) and returns the data
+(uint8 all_gather_into_tensor with a concatenated output -- raw descriptors and the packed prepared rows --, int32 gather to rank 0) and returns the data
 unchanged.  The multi-rank arithmetic is covered on CPU by tests/test_dist_pairs_gloo.py."""
 import os
 import socket
@@ -29,6 +29,14 @@ def test_rccl_collectives_world_of_one(cuda):
         local = torch.from_numpy(rng.integers(0, 256, (4, 512, 128), dtype=np.uint8)).to(dev)
         full = prs.all_gather_descriptors(local, always=True)
         assert full.shape == local.shape and torch.equal(full, local)
+        # bench.py's collective on the way in since round 3: the rank's PREPARED rows as one uint8 buffer
+        from image_stitcher_amd import ops
+        st, ct = np.arange(4, dtype=np.int64) * 512, np.full((4,), 512, np.int64)
+        Pl = ops.sort_rows_by_norm(ops.prepare_descriptor_tensor(local.reshape(-1, 128), st, ct))
+        P = prs.all_gather_prepared(Pl, st, ct, always=True)
+        assert P.desc.shape == Pl.desc.shape and P.desc.dtype == torch.int8 and P.desc.data_ptr() % 16 == 0
+        for a, b in ((P.desc, Pl.desc), (P.cbase, Pl.cbase), (P.nrm, Pl.nrm), (P.cin, Pl.cin)):
+            assert a.dtype == b.dtype and torch.equal(a, b)
         counts = torch.from_numpy(rng.integers(0, 4096, (37, 2)).astype(np.int32)).to(dev)
         allc = prs.gather_counts(counts, 37, 0, 1, always=True)
         assert allc.shape == (37, 2) and torch.equal(allc, counts)
