@@ -1329,7 +1329,9 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
 #define ISX_PAIR_T 0 /* compile-time timing diagnostics (tools/build_variant.sh), results WRONG when != 0: 4 no exact recounts,
                         16 report the candidate counts, 32 exactly 16 recounts per direction, 64 no chunk barrier */
 #endif
-#define ISX_PAIR_MAX_ROWS 4096
+#define ISX_PAIR_MAX_ROWS 4096   /* rows of either image for the four-group table (NG = 4) */
+#define ISX_PAIR_BIG_TRAIN 8192  /* NG = 2: rows of the smaller image of a pair (it becomes the train side) ... */
+#define ISX_PAIR_BIG_QUERY 16384 /* ... and of the larger one (128 classes of 128 query rows) */
 #ifndef ISX_PAIR_X
 #define ISX_PAIR_X 0 /* timing experiments on the step (WRONG results when != 0): 1 no sched_barrier per group, 2 no LDS atomics,
                         4 no DPP lane reduction, 8 no row-direction maxima, 16 the waves' LDS atomics land on different rows,
@@ -1338,7 +1340,7 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
 #endif
 #define ISX_B3 (1 << 22) /* bias of the packed row-direction bound: keeps it positive */
 #define ISX_PAIR_NBUF 4 /* staging buffers: the chunk being read, the next one (its first tile is read a step early), two in flight */
-#define ISX_PAIR_LDS (ISX_PAIR_NBUF * (128 * 128 + 128 * 4) + 256 + ISX_PAIR_MAX_ROWS * 16 + 64 * 4 + (4 + 2 * ISX_PAIR_CAP) * 4)
+#define ISX_PAIR_LDS (ISX_PAIR_NBUF * (128 * 128 + 128 * 4) + 256 + ISX_PAIR_MAX_ROWS * 16 + 128 * 2 * 4 + (4 + 2 * ISX_PAIR_CAP) * 4)
 
 __device__ __forceinline__ unsigned dpp_quad_max(unsigned v) { // maximum over each group of 4 lanes, in every lane
     unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true); // quad_perm [1,0,3,2]
@@ -1386,7 +1388,11 @@ __device__ __forceinline__ void top2_over_rows(unsigned &b1, unsigned &b2) {
 // by 2^-53; 2^-19 covers them with room.  (A NaN ratio compares false: the exact test decides.)
 __device__ __forceinline__ float ratio2_up(double ratio) { return __double2float_ru(ratio * ratio * (1.0 + 0x1p-19)); }
 
-template <int WAVES>
+// NG = groups per row of the table.  4: the kernel of BASELINE's 4096-keypoint images.  2: images beyond 4096 rows -- the table
+// keeps two groups per row (8 bytes: 8192 train rows in the same 64 KB; the second largest group maximum is a somewhat weaker
+// lower bound, so a few more candidates are recounted), the class tag takes 7 bits (128 classes = 16384 query rows), and the
+// smaller image of a pair is made the train side (results swapped back); a pair beyond those sizes is reported as (-1, -1).
+template <int WAVES, int NG>
 __global__ void __launch_bounds__(64 * WAVES)
 knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm, const int32_t *__restrict__ cin,
                         const isx_knn_item *__restrict__ items, int n_items, double ratio,
@@ -1397,21 +1403,36 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
     extern __shared__ __align__(16) unsigned char smem[];
     // (one dummy tile in front: the software pipeline's first fold runs on an all-zero accumulator of "tile -1")
     constexpr int NBUF = ISX_PAIR_NBUF;
-    unsigned *rowtab = (unsigned *)(smem + NBUF * BUF + 256);           // [ISX_PAIR_MAX_ROWS][4]: packed (bound << 5 | class)
-    int *cls = (int *)(smem + NBUF * BUF + 256 + ISX_PAIR_MAX_ROWS * 16);     // [32][2]: bound offset, 2 floor(nmin/2) - nmax
-    int *lst = cls + 64;                                             // n_col, n_row, good_col, good_row, col list, row list
+    static_assert(NG == 4 || NG == 2, "groups per table row");
+    constexpr int TAGB = NG == 4 ? 5 : 7, NCLS = 1 << TAGB; // class tag bits, classes (of 128 query rows)
+    constexpr int ROWB = NG * 4;                            // table bytes per train row
+    unsigned *rowtab = (unsigned *)(smem + NBUF * BUF + 256);           // [rows][NG]: packed (bound << TAGB | class)
+    int *cls = (int *)(smem + NBUF * BUF + 256 + ISX_PAIR_MAX_ROWS * 16);     // [NCLS][2]: bound offset, 2 floor(nmin/2) - nmax
+    int *lst = cls + 2 * 128;                                        // n_col, n_row, good_col, good_row, col list, row list
 
     const int item_i = blockIdx.x;
     if (item_i >= n_items) return;
-    const isx_knn_item it = items[item_i];
+    isx_knn_item it = items[item_i];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, col = lane & 15;
+    bool swapped = false;
+    if (NG == 2) {
+        if (it.nt > it.nq) { // the smaller image is the train side: its rows are what the table holds
+            const isx_knn_item o = it;
+            it.q_start = o.t_start, it.nq = o.nt, it.t_start = o.q_start, it.nt = o.nq;
+            swapped = true;
+        }
+        if (it.nt > ISX_PAIR_BIG_TRAIN || it.nq > ISX_PAIR_BIG_QUERY) { // (the caller runs both directions on the two-pass kernel)
+            if (tid == 0) count_out[2 * (int64_t)item_i] = count_out[2 * (int64_t)item_i + 1] = -1;
+            return;
+        }
+    }
     const int nt = it.nt, nq = it.nq;
     const int n_chunks = (nt + CHUNK - 1) / CHUNK;
     const int n_pass = (nq + QPB - 1) / QPB;
     const float r2_up = ratio2_up(ratio);
 
-    for (int i = tid; i < n_chunks * CHUNK; i += 64 * WAVES) ((uint4 *)rowtab)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < n_chunks * CHUNK * ROWB / 16; i += 64 * WAVES) ((uint4 *)rowtab)[i] = make_uint4(0u, 0u, 0u, 0u);
     if (tid < 4) lst[tid] = 0;
 
     const __amdgpu_buffer_rsrc_t rs_desc =
@@ -1470,7 +1491,8 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
     };
     // this lane's slot of the row table in tile 0 of chunk 0: row 4g + (lane & 3), group (lane >> 2) & 3
     // as an LDS byte address, one tile back (the dummy tile): the fold adds (tile + 1) * 256 + 16 r as an immediate
-    const unsigned row_slot_lds = smem_lds + NBUF * BUF + ((4 * g + (lane & 3)) * 4 + ((lane >> 2) & 3)) * 4;
+    // (NG == 2: group (lane >> 3) & 1, written by the lanes of the even quads only)
+    const unsigned row_slot_lds = smem_lds + NBUF * BUF + 256 - 16 * ROWB + (4 * g + (lane & 3)) * ROWB + (NG == 4 ? (lane >> 2) & 3 : (lane >> 3) & 1) * 4;
 
     v4i qf[NCB][2];
     unsigned phantom = 0; // bit cb: this lane's column of block cb is beyond nq
@@ -1520,7 +1542,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 }
             nmin = row16_min(nmin), nmax = row16_max(nmax); // (the 16 columns; the four row groups g hold the same values)
             const int off = ISX_B3 - (nmin >> 1);
-            kc = __builtin_amdgcn_readfirstlane((off << 5) | cls_id);
+            kc = __builtin_amdgcn_readfirstlane((off << TAGB) | cls_id);
             // a class whose norms spread widely (the two tails of a sorted image, every class of an unsorted one) would
             // make every row a candidate: it takes the per-value correction instead, which is exact to 1
             if (mode == 0 && __builtin_amdgcn_readfirstlane(nmax - nmin) > ISX_PAIR_SPREAD) mode = 1;
@@ -1546,7 +1568,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             // idles while both fold (counters: matrix pipe 51 % busy, 16 % of the cycles co-issued).
             // tile_c: compile-time index of tile P in the chunk, -1 .. 7 (-1 = the previous chunk's last tile, or the dummy tile)
             auto step = [&](const Frag &f, v4i (&X)[NCB], const v4i (&P)[NCB], unsigned slot_addr, auto tile_c) {
-                constexpr int TB = (decltype(tile_c)::value + 1) * 256;
+                constexpr int TB = (decltype(tile_c)::value + 1) * (16 * ROWB);
                 auto x = [&](int cb, int r) -> unsigned { // value of P for the row direction
                     unsigned v = (unsigned)P[cb][r];
                     if (MODE >= 1) v -= dq[cb];
@@ -1603,13 +1625,26 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                                      : "s"(0xCCCCCCCCCCCCCCCCull));
                     } else if (k == 6 && (ISX_PAIR_X & 2)) {
                         asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
-                    } else if (k == 6) {
+                    } else if (k == 6 && NG == 4) {
                         // the class's correction and tag, then the LDS max into the row table: lane -> (row 4g + (lane & 3),
                         // group (lane >> 2) & 3), 64 consecutive words per tile
                         asm volatile("v_lshl_add_u32 %0, %0, 5, %2\n\t"
                                      "ds_max_u32 %1, %0 offset:%3"
                                      : "+v"(w[0])
                                      : "v"(slot_addr), "s"(kcl), "n"(TB)
+                                     : "memory");
+                    } else if (k == 6) {
+                        // two groups per row: the even quads take their right-hand neighbours' maxima (lane + 4 holds the same
+                        // row) and write, 32 words per tile
+                        unsigned long long keep;
+                        asm volatile("v_max_u32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                     "v_lshl_add_u32 %1, %1, 7, %3\n\t"
+                                     "s_mov_b64 %0, exec\n\t"
+                                     "s_mov_b64 exec, %4\n\t"
+                                     "ds_max_u32 %2, %1 offset:%5\n\t"
+                                     "s_mov_b64 exec, %0"
+                                     : "=&s"(keep), "+v"(w[0])
+                                     : "v"(slot_addr), "s"(kcl), "s"(0x0F0F0F0F0F0F0F0Full), "n"(TB)
                                      : "memory");
                     }
                     if (!(ISX_PAIR_X & 1)) __builtin_amdgcn_sched_barrier(0);
@@ -1625,8 +1660,8 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 const int buf1 = (buf + 1) & (NBUF - 1);
                 if (c + NBUF - 1 < n_chunks) stage_chunk(c + NBUF - 1, (buf + NBUF - 1) & (NBUF - 1));
                 const unsigned char *base = smem + buf * BUF;
-                const unsigned slot_addr = (ISX_PAIR_X & 16) ? row_slot_lds + ((c * (CHUNK * 16) + wave * 8192) & 0xFFFF & ~2047)  // (diag: every wave its own rows)
-                                                             : row_slot_lds + c * (CHUNK * 16);
+                const unsigned slot_addr = (ISX_PAIR_X & 16) ? row_slot_lds + ((c * (CHUNK * ROWB) + wave * 8192) & 0xFFFF & ~2047)  // (diag: every wave its own rows)
+                                                             : row_slot_lds + c * (CHUNK * ROWB);
                 if (wave_live) {
                     auto two_tiles = [&](auto tc) {
                         constexpr int t = decltype(tc)::value;
@@ -1661,7 +1696,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             }
             // drain: fold the last tile (the matrix instructions of this extra step run on stale fragments into accA, unused)
             if (wave_live && n_chunks > 0)
-                step(f0, accA, accB, row_slot_lds + (n_chunks - 1) * (CHUNK * 16), std::integral_constant<int, 7>{});
+                step(f0, accA, accB, row_slot_lds + (n_chunks - 1) * (CHUNK * ROWB), std::integral_constant<int, 7>{});
         };
 
         __syncthreads(); // the first three chunks of this pass have landed (staged before the previous pass's epilogue)
@@ -1730,17 +1765,23 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
     __syncthreads();
     // row direction: candidates among the train image's rows, from the table
     for (int t = tid; t < nt; t += 64 * WAVES) {
-        const uint4 e = ((const uint4 *)rowtab)[t];
-        unsigned a = e.x > e.y ? e.x : e.y, b = e.x > e.y ? e.y : e.x;
-        unsigned c = e.z > e.w ? e.z : e.w, d = e.z > e.w ? e.w : e.z;
-        const unsigned E1 = a > c ? a : c;
-        const unsigned lo = a > c ? c : a, hi2 = b > d ? b : d;
-        const unsigned E2 = lo > hi2 ? lo : hi2;
+        unsigned E1, E2; // the largest and the second largest of the row's group maxima
+        if (NG == 4) {
+            const uint4 e = ((const uint4 *)rowtab)[t];
+            unsigned a = e.x > e.y ? e.x : e.y, b = e.x > e.y ? e.y : e.x;
+            unsigned c = e.z > e.w ? e.z : e.w, d = e.z > e.w ? e.w : e.z;
+            E1 = a > c ? a : c;
+            const unsigned lo = a > c ? c : a, hi2 = b > d ? b : d;
+            E2 = lo > hi2 ? lo : hi2;
+        } else {
+            const uint2 e = ((const uint2 *)rowtab)[t];
+            E1 = e.x > e.y ? e.x : e.y, E2 = e.x > e.y ? e.y : e.x;
+        }
         if (E1 == 0u) continue; // no query row at all
-        // entry >> 5 = raw + ISX_B3 - floor(nmin_c / 2), raw = B2 + t.q - ceil(n_t / 2); squared distance s = 2 B2 - p_t - (2 raw - n_q)
-        const int c1 = E1 & 31, c2 = E2 & 31;
-        const int u1 = (int)(E1 >> 5) - ISX_B3, u2 = (int)(E2 >> 5) - ISX_B3; // raw - floor(nmin_c / 2): 2 u >= 2 raw - n_q in the class
-        const int raw2 = (int)(E2 >> 5) - cls[2 * c2];
+        // entry >> TAGB = raw + ISX_B3 - floor(nmin_c / 2), raw = B2 + t.q - ceil(n_t / 2); squared distance s = 2 B2 - p_t - (2 raw - n_q)
+        const int c1 = E1 & (NCLS - 1), c2 = E2 & (NCLS - 1);
+        const int u1 = (int)(E1 >> TAGB) - ISX_B3, u2 = (int)(E2 >> TAGB) - ISX_B3; // raw - floor(nmin_c / 2): 2 u >= 2 raw - n_q in the class
+        const int raw2 = (int)(E2 >> TAGB) - cls[2 * c2];
         bool cand = true;                                      // fewer than two real entries: the exact scan decides
         if (E2 != 0u && raw2 >= (1 << 20) && !(flags & 1)) {   // (raw of a real query row is >= 2^20; masked columns give 0)
             // the two entries belong to two distinct query rows whose 2 raw - n_q is at least 2 u + (2 floor(nmin/2) - nmax)
@@ -1785,8 +1826,9 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
     }
     __syncthreads();
     if (tid == 0) {
-        count_out[2 * (int64_t)item_i] = (ISX_PAIR_T & 16) ? n_col : n_col <= ISX_PAIR_CAP ? lst[2] : -1;
-        count_out[2 * (int64_t)item_i + 1] = (ISX_PAIR_T & 16) ? n_row : n_row <= ISX_PAIR_CAP ? lst[3] : -1;
+        // ([2e] = the direction whose queries are the ITEM's q image: the column direction unless the roles were swapped)
+        count_out[2 * (int64_t)item_i + (swapped ? 1 : 0)] = (ISX_PAIR_T & 16) ? n_col : n_col <= ISX_PAIR_CAP ? lst[2] : -1;
+        count_out[2 * (int64_t)item_i + (swapped ? 0 : 1)] = (ISX_PAIR_T & 16) ? n_row : n_row <= ISX_PAIR_CAP ? lst[3] : -1;
     }
 }
 
@@ -1795,19 +1837,25 @@ extern "C" int isx_knn2_l2_count_pairs(const int8_t *desc_dev, const int32_t *nr
                                        int32_t *count_out_dev, int flags, void *stream) {
     ISX_REQUIRE(d_pad == 128, "isx_knn2_l2_count_pairs needs 128-byte rows (got d_pad %d)", d_pad);
     ISX_REQUIRE(n_items >= 0 && max_rows >= 0, "negative size");
-    ISX_REQUIRE(max_rows <= ISX_PAIR_MAX_ROWS, "isx_knn2_l2_count_pairs takes images of at most %d rows (got %d): use isx_knn2_l2_count_items",
-                ISX_PAIR_MAX_ROWS, max_rows);
     if (n_items == 0 || max_rows == 0) return ISX_OK;
     ISX_REQUIRE(desc_dev && nrm_dev && cin_dev && items_dev && count_out_dev, "null device pointer");
     ISX_REQUIRE(((uintptr_t)desc_dev & 15) == 0, "desc_dev must be 16-byte aligned");
     constexpr int WAVES = 8;
-    ISX_HIP_TRY(hipFuncSetAttribute((const void *)knn2_pair_filter_kernel<WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, ISX_PAIR_LDS));
+    // images of up to 4096 rows: the four-group table.  Beyond: two groups per row (a pair whose smaller image has more than
+    // 8192 rows or whose larger one more than 16384 comes back as (-1, -1), like any other direction the caller re-runs)
+    const bool big = max_rows > ISX_PAIR_MAX_ROWS;
+    const void *fn = big ? (const void *)knn2_pair_filter_kernel<WAVES, 2> : (const void *)knn2_pair_filter_kernel<WAVES, 4>;
+    ISX_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ISX_PAIR_LDS));
     const int per = isx_items_per_launch(1, 64 * WAVES);
     hipStream_t st = (hipStream_t)stream;
     for (int off = 0; off < n_items; off += per) {
         const int n = n_items - off < per ? n_items - off : per;
-        hipLaunchKernelGGL((knn2_pair_filter_kernel<WAVES>), dim3((unsigned)n), dim3(64 * WAVES), ISX_PAIR_LDS, st, desc_dev, nrm_dev,
-                           cin_dev, items_dev + off, n, ratio, count_out_dev + 2 * (int64_t)off, flags);
+        if (big)
+            hipLaunchKernelGGL((knn2_pair_filter_kernel<WAVES, 2>), dim3((unsigned)n), dim3(64 * WAVES), ISX_PAIR_LDS, st, desc_dev,
+                               nrm_dev, cin_dev, items_dev + off, n, ratio, count_out_dev + 2 * (int64_t)off, flags);
+        else
+            hipLaunchKernelGGL((knn2_pair_filter_kernel<WAVES, 4>), dim3((unsigned)n), dim3(64 * WAVES), ISX_PAIR_LDS, st, desc_dev,
+                               nrm_dev, cin_dev, items_dev + off, n, ratio, count_out_dev + 2 * (int64_t)off, flags);
     }
     return isx_launch_status("knn2_pair_filter_kernel");
 }

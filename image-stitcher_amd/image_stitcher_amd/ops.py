@@ -154,14 +154,22 @@ def sort_rows_by_norm(P):
 
 
 FRAME_MAX_Q = 32768    # include/isx.h ISX_FRAME_MAX_Q: largest side of the rectangle isx_frame_blend warps into
-PAIR_MAX_ROWS = 4096   # isx_knn2_l2_count_pairs: rows per image (its per-row table lives in LDS)
+PAIR_MAX_ROWS = 4096   # isx_knn2_l2_count_pairs: rows per image for its four-group table (the per-row table lives in LDS)
+PAIR_BIG_TRAIN, PAIR_BIG_QUERY = 8192, 16384  # beyond: two groups per row -- rows of the smaller / the larger image of a pair
 PAIR_MIN_ITEMS = 2048  # below this many pairs the one-workgroup-per-pair kernel cannot fill the chip: use the directed kernel
 
 
 def pairs_kernel_applies(P, pair_items):
     """True when the both-directions kernel (isx_knn2_l2_count_pairs) can and should run this pair list."""
     it = np.asarray(pair_items).reshape(-1, 4)
-    return (not P.wide) and P.d_pad == 128 and len(it) >= PAIR_MIN_ITEMS and int(max(it[:, 1].max(), it[:, 3].max())) <= PAIR_MAX_ROWS
+    if P.wide or P.d_pad != 128 or len(it) < PAIR_MIN_ITEMS:
+        return False
+    lo, hi = np.minimum(it[:, 1], it[:, 3]), np.maximum(it[:, 1], it[:, 3])
+    if int(hi.max()) <= PAIR_MAX_ROWS:
+        return True
+    # larger images: the kernel hands a pair it cannot hold back as (-1, -1) and knn2_l2_pairs re-runs it on the directed kernel;
+    # worth a launch when most pairs fit
+    return float(np.mean((lo <= PAIR_BIG_TRAIN) & (hi <= PAIR_BIG_QUERY))) >= 0.5
 
 
 def knn2_l2_pairs(P, pair_items, ratio, plan=None, events=None, flags=0, stats=None):

@@ -128,7 +128,9 @@ int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, cons
  *   -1 = that direction has more than 128 candidates (the images overlap), or the other direction of the pair had and
  *        the kernel left the pair early: the caller runs it as an item of isx_knn2_l2_count_items.  Every other value
  *        is the exact count (same as isx_knn2_l2_count_items).
- * count_out_dev need not be zeroed.  d_pad must be 128 and max_rows (max over items of nq and nt) <= 4096.  Rows sorted
+ * count_out_dev need not be zeroed.  d_pad must be 128.  max_rows = max over items of nq and nt: up to 4096 the kernel keeps
+ * four group maxima per row; beyond, two (a few more candidates are recounted), the smaller image of a pair is made the train
+ * side, and a pair whose smaller image has more than 8192 rows or whose larger one more than 16384 comes back as (-1, -1).  Rows sorted
  * by nrm inside each image keep the candidate lists short (counts do not depend on the row order); any order is exact.
  * flags bit 0 = test hook: every query is a candidate. */
 int isx_knn2_l2_count_pairs(const int8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev, int d_pad,

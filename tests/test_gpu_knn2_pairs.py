@@ -104,8 +104,35 @@ def test_sorted_rows_leave_counts_unchanged_and_shrink_the_candidate_lists(cuda)
 def test_pairs_kernel_refuses_what_it_cannot_run(cuda):
     from image_stitcher_amd import ops
     from image_stitcher_amd._lib import IsxError
-    des = _ragged_set(1, [4097, 10])
+    des = _ragged_set(1, [300, 10], d=64)
     P = ops.prepare_descriptors(des)
-    with pytest.raises(IsxError):
-        ops.knn2_l2_pairs(P, np.array([[0, 4097, 4097, 10]], np.int32), 0.65)
-    assert not ops.pairs_kernel_applies(P, np.array([[0, 4097, 4097, 10]] * 5000, np.int32))
+    with pytest.raises(IsxError):  # 64-byte rows
+        ops.knn2_l2_pairs(P, np.array([[0, 300, 300, 10]], np.int32), 0.65)
+    assert not ops.pairs_kernel_applies(P, np.array([[0, 300, 300, 10]] * 5000, np.int32))
+    # images the two-group table cannot hold either: more than half of the pairs -> not worth the launch
+    P128 = ops.prepare_descriptors(_ragged_set(2, [40, 10]))
+    assert not ops.pairs_kernel_applies(P128, np.array([[0, 9000, 9000, 8500]] * 5000, np.int32))
+    assert ops.pairs_kernel_applies(P128, np.array([[0, 9000, 9000, 8000]] * 5000, np.int32))
+
+
+@pytest.mark.parametrize("sort_rows", [False, True])
+def test_pairs_kernel_images_beyond_4096_rows(cuda, orc, sort_rows):
+    """Images of more than 4096 rows (cv2.SIFT_create() does not cap the keypoints): the two-group table takes a smaller
+    image of up to 8192 rows as the train side -- whichever side of the item it is -- and a larger one of up to 16384 rows in
+    up to 16 passes; what it cannot hold (here 8300 x 9000) comes back as (-1, -1) and is re-run on the directed kernel by
+    ops.knn2_l2_pairs.  Exact counts against the oracle, both directions, both item orientations."""
+    from image_stitcher_amd import ops
+    sizes = [4097, 8192, 700, 12000, 8300, 9000, 5000, 1]
+    des = _ragged_set(9, sizes, dup_frac=0.05)
+    P = ops.prepare_descriptors(des)
+    if sort_rows:
+        P = ops.sort_rows_by_norm(P)
+    st, ct = np.asarray(P.starts), np.asarray(P.counts)
+    pairs = [(0, 1), (1, 0), (2, 3), (3, 2), (4, 5), (1, 3), (3, 1), (6, 0), (7, 3), (3, 7), (6, 2), (4, 2)]
+    items = np.array([(st[i], ct[i], st[j], ct[j]) for i, j in pairs], np.int32)
+    want = _oracle_counts(orc, des, pairs, 0.8)
+    assert want.max() > 20
+    stt = {}
+    got = ops.knn2_l2_pairs(P, items, 0.8, stats=stt).cpu().numpy()
+    assert np.array_equal(got, want), (got.tolist(), want.tolist())
+    assert stt["overflow_directions"] >= 2  # at least the 8300 x 9000 pair

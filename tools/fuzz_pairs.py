@@ -20,6 +20,10 @@ def one_case(seed):
     pick = lambda: int(rng.choice([1, 2, 16, 127, 128, 129, 1023, 1024, 1025, 2048, 2049, 3000, 4095, 4096,
                                    int(rng.integers(3, 4097))]))
     sizes = [pick() for _ in range(n_img)]
+    if rng.random() < 0.2:  # images beyond 4096 rows: the two-group table (train side <= 8192 rows, query side <= 16384)
+        sizes[int(rng.integers(0, n_img))] = int(rng.choice([4097, 6000, 8192, 8193, 12000, 16384, 16385]))
+        if rng.random() < 0.5:
+            sizes[int(rng.integers(0, n_img))] = int(rng.choice([4097, 5000, 8192, 9000]))
     if rng.random() < 0.5:  # SIFT-like rows (a wide norm range) instead of uniform ones
         from image_stitcher_amd.synthetic import sift_like_pool
         pool = sift_like_pool(rng, 4096, d)
