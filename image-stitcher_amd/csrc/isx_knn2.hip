@@ -1703,7 +1703,10 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
         // Overlapping images: once the column direction has overflowed its candidate list the pair goes to the two-pass
         // kernel anyway -- leave now (both directions reported as -1) instead of forming the remaining products.  The
         // barrier above has drained this wave's DMA; lst[0] only changes in the column epilogue, before that barrier.
-        if (pass > 0 && lst[0] > ISX_PAIR_CAP && !(ISX_PAIR_T & 20)) {
+        // "Overflowed" is taken as "on course to overflow": more than pass / n_pass of the list is used after `pass` passes.  Leaving
+        // is always safe (the two-pass kernel is exact), and for a pair that would have stayed just below the limit the
+        // recounts it is spared cost about what the two-pass items do.
+        if (pass > 0 && lst[0] * n_pass > ISX_PAIR_CAP * pass && !(ISX_PAIR_T & 20)) {
             if (tid == 0) count_out[2 * (int64_t)item_i] = count_out[2 * (int64_t)item_i + 1] = -1;
             return;
         }
