@@ -1388,6 +1388,71 @@ __device__ __forceinline__ void top2_over_rows(unsigned &b1, unsigned &b2) {
 // by 2^-53; 2^-19 covers them with room.  (A NaN ratio compares false: the exact test decides.)
 __device__ __forceinline__ float ratio2_up(double ratio) { return __double2float_ru(ratio * ratio * (1.0 + 0x1p-19)); }
 
+// Exact recount of up to 16 candidate queries by ONE wave on the matrix pipe: the wave walks the other image once (16-row
+// tiles straight from global memory, 8 tiles in flight) and keeps, per query, the exact two largest values 2 a.b - n_b of its
+// rows -- the same values, hence the same verdicts, as knn2_exact_scan128, which walks the image once PER QUERY: 512 KB each,
+// and with eight waves of a CU recounting at once that walk is bound by the CU's load path (~90 us per query measured, 3 ms for
+// a pair with two full candidate lists).  qlist: up to 16 query rows (indices inside the query image, in LDS).  Returns the
+// number of good matches among them (wave-uniform).
+struct __attribute__((packed, aligned(4))) isx_i4u { int v[4]; };
+__device__ __noinline__ int knn2_exact_recount16(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm, const int *qlist,
+                                                 int n_q, int q_start, int t_start, int nt, int lane, double ratio) {
+    constexpr int PF = 8;
+    const int col = lane & 15, g = lane >> 4;
+    const bool have = col < n_q;
+    const int qrow = q_start + qlist[have ? col : 0];
+    const v4i *qp = (const v4i *)(desc + (int64_t)qrow * 128);
+    const v4i b0 = qp[g], b1 = qp[4 + g];
+    const int n_tiles = (nt + 15) >> 4;
+    v4i a0[PF], a1[PF];
+    isx_i4u nb[PF];
+    auto load = [&](int t, int s) {
+        const int row = 16 * t + col;
+        const v4i *tp = (const v4i *)(desc + (int64_t)(t_start + (row < nt ? row : nt - 1)) * 128);
+        a0[s] = tp[g];
+        a1[s] = tp[4 + g];
+        const int r0 = 16 * t + 4 * g; // this lane's four output rows
+        if (r0 + 3 < nt)
+            nb[s] = *(const isx_i4u *)(nrm + t_start + r0);
+        else // the image's last rows: one guarded load per row (never past the image)
+#pragma unroll
+            for (int i = 0; i < 4; i++) nb[s].v[i] = r0 + i < nt ? nrm[t_start + r0 + i] : 0;
+    };
+#pragma unroll
+    for (int s = 0; s < PF; s++)
+        if (s < n_tiles) load(s, s);
+    int m1 = INT32_MIN, m2 = INT32_MIN;
+    for (int t0 = 0; t0 < n_tiles; t0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; s++) {
+            const int t = t0 + s;
+            if (t >= n_tiles) break;
+            v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[s], b0, v4i{0, 0, 0, 0}, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[s], b1, acc, 0, 0, 0);
+            const int r0 = 16 * t + 4 * g;
+            const int nbv[4] = {nb[s].v[0], nb[s].v[1], nb[s].v[2], nb[s].v[3]};
+            if (t + PF < n_tiles) load(t + PF, s);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int v = (r0 + i < nt) ? 2 * acc[i] - nbv[i] : INT32_MIN;
+                const int lo = m1 < v ? m1 : v;
+                m1 = m1 < v ? v : m1;
+                m2 = m2 < lo ? lo : m2;
+            }
+        }
+    }
+    // merge the four row groups of a column (signed values through the unsigned helper: x ^ 0x80000000 keeps the order)
+    unsigned u1 = (unsigned)m1 ^ 0x80000000u, u2 = (unsigned)m2 ^ 0x80000000u;
+    top2_over_rows(u1, u2);
+    const int v1 = (int)(u1 ^ 0x80000000u), v2 = (int)(u2 ^ 0x80000000u);
+    bool good = false;
+    if (g == 0 && have) {
+        const int na = nrm[qrow];
+        good = (v1 != INT32_MIN) && (v2 == INT32_MIN || ratio_good(na - v1, na - v2, ratio));
+    }
+    return __builtin_popcountll(__builtin_amdgcn_ballot_w64(good));
+}
+
 // NG = groups per row of the table.  4: the kernel of BASELINE's 4096-keypoint images.  2: images beyond 4096 rows -- the table
 // keeps two groups per row (8 bytes: 8192 train rows in the same 64 KB; the second largest group maximum is a somewhat weaker
 // lower bound, so a few more candidates are recounted), the class tag takes 7 bits (128 classes = 16384 query rows), and the
@@ -1807,22 +1872,19 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
     }
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     int good_col = 0, good_row = 0;
-    if (n_col <= ISX_PAIR_CAP && !(ISX_PAIR_T & 4))
-        for (int k = wv; k < n_col; k += WAVES) {
-            const int qi = lst[4 + k];
-            int v1, v2;
-            knn2_exact_scan128(desc, nrm, it.q_start + qi, it.t_start, nt, lane, v1, v2);
-            const int na = nrm[it.q_start + qi];
-            good_col += (v1 != INT32_MIN) && (v2 == INT32_MIN || ratio_good(na - v1, na - v2, ratio));
-        }
-    if (n_row <= ISX_PAIR_CAP && !(ISX_PAIR_T & 4))
-        for (int k = wv; k < n_row; k += WAVES) {
-            const int t = lst[4 + ISX_PAIR_CAP + k];
-            int v1, v2;
-            knn2_exact_scan128(desc, nrm, it.t_start + t, it.q_start, nq, lane, v1, v2);
-            const int na = nrm[it.t_start + t];
-            good_row += (v1 != INT32_MIN) && (v2 == INT32_MIN || ratio_good(na - v1, na - v2, ratio));
-        }
+    // exact recounts, up to 16 candidates per wave and walk of the other image; the lists are spread evenly over the waves
+    if (n_col <= ISX_PAIR_CAP && !(ISX_PAIR_T & 4)) {
+        const int gsz = n_col > 16 * WAVES ? 16 : (n_col + WAVES - 1) / WAVES;
+        for (int k0 = wv * gsz; k0 < n_col; k0 += WAVES * gsz)
+            good_col += knn2_exact_recount16(desc, nrm, lst + 4 + k0, n_col - k0 < gsz ? n_col - k0 : gsz, it.q_start, it.t_start,
+                                             nt, lane, ratio);
+    }
+    if (n_row <= ISX_PAIR_CAP && !(ISX_PAIR_T & 4)) {
+        const int gsz = n_row > 16 * WAVES ? 16 : (n_row + WAVES - 1) / WAVES;
+        for (int k0 = wv * gsz; k0 < n_row; k0 += WAVES * gsz)
+            good_row += knn2_exact_recount16(desc, nrm, lst + 4 + ISX_PAIR_CAP + k0, n_row - k0 < gsz ? n_row - k0 : gsz, it.t_start,
+                                             it.q_start, nq, lane, ratio);
+    }
     if (lane == 0) {
         if (good_col) atomicAdd(&lst[2], good_col);
         if (good_row) atomicAdd(&lst[3], good_row);

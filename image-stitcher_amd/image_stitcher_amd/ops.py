@@ -156,7 +156,7 @@ def sort_rows_by_norm(P):
 FRAME_MAX_Q = 32768    # include/isx.h ISX_FRAME_MAX_Q: largest side of the rectangle isx_frame_blend warps into
 PAIR_MAX_ROWS = 4096   # isx_knn2_l2_count_pairs: rows per image for its four-group table (the per-row table lives in LDS)
 PAIR_BIG_TRAIN, PAIR_BIG_QUERY = 8192, 16384  # beyond: two groups per row -- rows of the smaller / the larger image of a pair
-PAIR_MIN_ITEMS = 2048  # below this many pairs the one-workgroup-per-pair kernel cannot fill the chip: use the directed kernel
+PAIR_MIN_ITEMS = 512   # below this many pairs the one-workgroup-per-pair kernel does not beat the directed kernel (tools/pairs_min_items.py)
 
 
 def pairs_kernel_applies(P, pair_items):
