@@ -436,6 +436,81 @@ __device__ __forceinline__ void jacobi_lds(double *A, double *V, double *W, int 
     __syncthreads();
 }
 
+// Eigenvector of the SMALLEST eigenvalue of the symmetric positive semi-definite 9 x 9 matrix given by its upper triangle
+// (acc[u], rows j <= k in order), by inverse iteration on an LDL^T factorisation held in registers: every index is a compile-time
+// constant, every lane computes the same thing (no LDS, no barrier).  The DLT's LtL has one eigenvalue near zero and the next
+// one orders of magnitude above it, so the iteration settles in two or three steps; it returns false when 24 steps do not
+// (two comparably small eigenvalues: a degenerate point set) and the caller falls back to the Jacobi sweep, which the refit
+// used for every frame before (cyclic Jacobi in LDS: ~70 us of three barriers and two hypot per rotation).
+__device__ __forceinline__ bool smallest_eigvec9(const double (&acc)[45], double (&x)[9]) {
+    double A[9][9];
+    {
+        int u = 0;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+#pragma unroll
+            for (int k = j; k < 9; k++) A[k][j] = acc[u++]; // lower triangle
+    }
+    double dmax = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) dmax = fmax(dmax, A[j][j]);
+    const double floor_d = dmax * 1e-18 + 1e-300;
+    double L[9][9], LD[9][9], invD[9]; // L unit lower triangular, LD[i][k] = L[i][k] * D[k]
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= L[j][k] * LD[j][k];
+        if (!(d > floor_d)) d = floor_d; // (the near-zero eigenvalue shows up as the last pivot; rounding may push it below 0)
+        invD[j] = 1. / d;
+#pragma unroll
+        for (int i = j + 1; i < 9; i++) {
+            double v = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[i][k] * LD[j][k];
+            LD[i][j] = v;
+            L[i][j] = v * invD[j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) x[i] = 1. / 3. + 0.01 * i;
+    bool settled = false;
+    for (int it = 0; it < 24; it++) {
+        double y[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) { // L y = x
+            double v = x[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) v -= L[i][k] * y[k];
+            y[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++) y[i] *= invD[i];
+#pragma unroll
+        for (int i = 8; i >= 0; i--) { // L^T w = y (in place)
+            double v = y[i];
+#pragma unroll
+            for (int k = i + 1; k < 9; k++) v -= L[k][i] * y[k];
+            y[i] = v;
+        }
+        double nn = 0, dot = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nn += y[i] * y[i], dot += y[i] * x[i];
+        const double sc = (dot < 0 ? -1. : 1.) / sqrt(nn);
+        double diff = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const double v = y[i] * sc;
+            diff = fmax(diff, fabs(v - x[i]));
+            x[i] = v;
+        }
+        if (!(nn > 0) || nn != nn) return false;
+        if (settled) return true; // one step past the first that moved by less than 1e-13
+        settled = diff < 1e-13;
+    }
+    return false;
+}
+
 // Gaussian elimination with partial pivoting on lane 0 (n <= 8), Ab is n x (n+1) in LDS; x out
 __device__ __forceinline__ void solve_ge(double *Ab, double *x, int n) {
     const int w = n + 1;
@@ -652,13 +727,19 @@ __device__ __forceinline__ void lm_run(RefineShared &sh, const float2 *src, cons
                 nu = fmin(fmax(nu, 2.), 10.);
                 if (sh.lambda == 0) {
                     double maxval = DBL_EPSILON;
-                    for (int i = 0; i < NP; i++) { // diagonal of inv(JtJ)
+                    // diagonal of inv(JtJ): NP solves, in registers like the step's own (solve_ge_reg: the same arithmetic in the
+                    // same order as solve_ge on the LDS copy, which took 25 us per 8 x 8 solve -- 200 us of a homography
+                    // refinement whenever lambda reached 0, i.e. whenever LM starts close to its optimum, as it does after the refit)
+#pragma unroll 1
+                    for (int i = 0; i < NP; i++) {
+                        double Abi[NP][NP + 1], col[NP];
+#pragma unroll
                         for (int a = 0; a < NP; a++) {
-                            for (int b = 0; b < NP; b++) sh.Ab[a * (NP + 1) + b] = sh.JtJ[a * NP + b];
-                            sh.Ab[a * (NP + 1) + NP] = a == i ? 1. : 0.;
+#pragma unroll
+                            for (int b = 0; b < NP; b++) Abi[a][b] = sh.JtJ[a * NP + b];
+                            Abi[a][NP] = a == i ? 1. : 0.;
                         }
-                        double col[NP];
-                        solve_ge(sh.Ab, col, NP);
+                        solve_ge_reg<NP>(Abi, col);
                         double ci = 0;
 #pragma unroll
                         for (int a = 0; a < NP; a++)
@@ -762,26 +843,35 @@ __global__ void __launch_bounds__(64) ransac_refine_kernel(int model, double *__
                 }
 #pragma unroll
                 for (int i = 0; i < 45; i++) acc[i] = wsum(acc[i]);
-                if (lane == 0) {
-                    int u = 0;
+                double hv[9];
+                const bool quick = smallest_eigvec9(acc, hv); // (wave-uniform: every lane holds the same sums)
+                if (!quick) {
+                    if (lane == 0) {
+                        int u = 0;
 #pragma unroll
-                    for (int j = 0; j < 9; j++) {
+                        for (int j = 0; j < 9; j++) {
 #pragma unroll
-                        for (int k = j; k < 9; k++) {
-                            sh.A[j * 9 + k] = acc[u];
-                            sh.A[k * 9 + j] = acc[u];
-                            u++;
+                            for (int k = j; k < 9; k++) {
+                                sh.A[j * 9 + k] = acc[u];
+                                sh.A[k * 9 + j] = acc[u];
+                                u++;
+                            }
                         }
                     }
+                    __syncthreads();
+                    jacobi_lds(sh.A, sh.V, sh.W, 9, lane);
                 }
-                __syncthreads();
-                jacobi_lds(sh.A, sh.V, sh.W, 9, lane);
                 if (lane == 0) {
-                    int best = 0;
-                    for (int i = 1; i < 9; i++)
-                        if (sh.W[i] < sh.W[best]) best = i;
                     double h[9], H[9];
-                    for (int i = 0; i < 9; i++) h[i] = sh.V[best * 9 + i];
+                    if (quick) {
+#pragma unroll
+                        for (int i = 0; i < 9; i++) h[i] = hv[i];
+                    } else {
+                        int best = 0;
+                        for (int i = 1; i < 9; i++)
+                            if (sh.W[i] < sh.W[best]) best = i;
+                        for (int i = 0; i < 9; i++) h[i] = sh.V[best * 9 + i];
+                    }
                     denormalise(h, N, H);
                     for (int i = 0; i < 9; i++) M[i] = H[i];
                 }
