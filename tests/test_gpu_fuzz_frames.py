@@ -43,3 +43,12 @@ def test_fuzz_pair_kernel_against_the_oracle(cuda, orc):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
     import fuzz_pairs
     assert fuzz_pairs.main(20, 180000) == 0
+
+
+def test_fuzz_robust_transform_against_the_oracle(cuda, orc):
+    """tools/fuzz_ransac.py: get_transform (both models) against the oracle's sequential RANSAC on random point counts, outlier
+    fractions and noise levels: the same inlier masks everywhere, M within 1e-3 px on well-determined sets (700 cases ran with
+    the same verdicts on the round's final build and on the build before the refit / LM changes)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import fuzz_ransac
+    assert fuzz_ransac.main(40, 330000) == 0
