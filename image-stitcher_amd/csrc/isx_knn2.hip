@@ -1395,22 +1395,24 @@ __device__ __forceinline__ float ratio2_up(double ratio) { return __double2float
 // a pair with two full candidate lists).  qlist: up to 16 query rows (indices inside the query image, in LDS).  Returns the
 // number of good matches among them (wave-uniform).
 struct __attribute__((packed, aligned(4))) isx_i4u { int v[4]; };
+template <int KS> // 64-byte K steps of a row: 2 = 128-byte rows, 1 = 64-byte rows
 __device__ __noinline__ int knn2_exact_recount16(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm, const int *qlist,
                                                  int n_q, int q_start, int t_start, int nt, int lane, double ratio) {
     constexpr int PF = 8;
     const int col = lane & 15, g = lane >> 4;
     const bool have = col < n_q;
     const int qrow = q_start + qlist[have ? col : 0];
-    const v4i *qp = (const v4i *)(desc + (int64_t)qrow * 128);
-    const v4i b0 = qp[g], b1 = qp[4 + g];
+    constexpr int DP = 64 * KS;
+    const v4i *qp = (const v4i *)(desc + (int64_t)qrow * DP);
+    const v4i b0 = qp[g], b1 = KS == 2 ? qp[4 + g] : v4i{0, 0, 0, 0};
     const int n_tiles = (nt + 15) >> 4;
     v4i a0[PF], a1[PF];
     isx_i4u nb[PF];
     auto load = [&](int t, int s) {
         const int row = 16 * t + col;
-        const v4i *tp = (const v4i *)(desc + (int64_t)(t_start + (row < nt ? row : nt - 1)) * 128);
+        const v4i *tp = (const v4i *)(desc + (int64_t)(t_start + (row < nt ? row : nt - 1)) * DP);
         a0[s] = tp[g];
-        a1[s] = tp[4 + g];
+        if (KS == 2) a1[s] = tp[4 + g];
         const int r0 = 16 * t + 4 * g; // this lane's four output rows
         if (r0 + 3 < nt)
             nb[s] = *(const isx_i4u *)(nrm + t_start + r0);
@@ -1428,7 +1430,7 @@ __device__ __noinline__ int knn2_exact_recount16(const int8_t *__restrict__ desc
             const int t = t0 + s;
             if (t >= n_tiles) break;
             v4i acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[s], b0, v4i{0, 0, 0, 0}, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[s], b1, acc, 0, 0, 0);
+            if (KS == 2) acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[s], b1, acc, 0, 0, 0);
             const int r0 = 16 * t + 4 * g;
             const int nbv[4] = {nb[s].v[0], nb[s].v[1], nb[s].v[2], nb[s].v[3]};
             if (t + PF < n_tiles) load(t + PF, s);
@@ -1457,12 +1459,15 @@ __device__ __noinline__ int knn2_exact_recount16(const int8_t *__restrict__ desc
 // keeps two groups per row (8 bytes: 8192 train rows in the same 64 KB; the second largest group maximum is a somewhat weaker
 // lower bound, so a few more candidates are recounted), the class tag takes 7 bits (128 classes = 16384 query rows), and the
 // smaller image of a pair is made the train side (results swapped back); a pair beyond those sizes is reported as (-1, -1).
-template <int WAVES, int NG>
+// KS = 64-byte K steps of a descriptor row: 2 = 128-byte rows (SIFT), 1 = 64-byte rows (AKAZE's 61 bytes, padded): one matrix
+// instruction per tile and column block, the same folds.
+template <int WAVES, int NG, int KS>
 __global__ void __launch_bounds__(64 * WAVES)
 knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm, const int32_t *__restrict__ cin,
                         const isx_knn_item *__restrict__ items, int n_items, double ratio,
                         int32_t *__restrict__ count_out, int flags) {
-    constexpr int DP = 128, SLOTS = 8, SH = 1, CHUNK = 128, NCB = 8;
+    static_assert(KS == 1 || KS == 2, "64- or 128-byte rows");
+    constexpr int DP = 64 * KS, SLOTS = DP / 16, SH = KS == 2 ? 1 : 2, CHUNK = 128, NCB = 8;
     constexpr int BUF = CHUNK * DP + CHUNK * 4;
     constexpr int QPW = 16 * NCB, QPB = WAVES * QPW;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1527,7 +1532,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_cin, (lds_ptr_t)(smem_lds + bufi * BUF + CHUNK * DP + (wv & 1) * 256), 4,
                                                  lane * 4, c * (CHUNK * 4) + (wv & 1) * 256, 0, 0);
     };
-    static_assert(PIECES % WAVES == 0 && PPW + 1 == 3, "the counted waits below assume 3 DMA instructions per wave and stage");
+    static_assert(PIECES % WAVES == 0 && PPW + 1 == KS + 1, "the counted waits below assume KS + 1 DMA instructions per wave and stage");
     auto stage_first = [&]() { // the chunks a pass starts on
 #pragma unroll
         for (int c = 0; c < NBUF - 1; c++)
@@ -1551,7 +1556,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             return;
         }
         f.a[0] = *(const v4i *)(base + fo0 + t * (16 * DP));
-        f.a[1] = *(const v4i *)(base + fo1 + t * (16 * DP));
+        if (KS == 2) f.a[1] = *(const v4i *)(base + fo1 + t * (16 * DP));
         f.cv = *(const v4i *)(base + foc + t * 64);
     };
     // this lane's slot of the row table in tile 0 of chunk 0: row 4g + (lane & 3), group (lane >> 2) & 3
@@ -1573,7 +1578,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             const int qi = q0 + cb * 16 + col;
             const v4i *p = (const v4i *)(desc + (int64_t)(it.q_start + (qi < nq ? qi : 0)) * DP);
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++) qf[cb][ks] = (qi < nq) ? p[4 * ks + g] : v4i{0, 0, 0, 0};
+            for (int ks = 0; ks < KS; ks++) qf[cb][ks] = (qi < nq) ? p[4 * ks + g] : v4i{0, 0, 0, 0};
             na_nx[cb] = qi < nq ? nrm[it.q_start + qi] : -1;
             if (qi >= nq) phantom |= 1u << cb;
         }
@@ -1644,7 +1649,11 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 const int kcl = kc; // (a plain use: clang does not capture a variable that only appears as an asm operand)
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    X[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[0], qf[k][0], f.cv, 0, 0, 0);
+                    // (64-byte rows: eight matrix instructions per step, spread over the sixteen slots of the fold)
+                    if (KS == 2)
+                        X[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[0], qf[k][0], f.cv, 0, 0, 0);
+                    else if ((k & 1) == 0)
+                        X[k / 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[0], qf[k / 2][0], f.cv, 0, 0, 0);
                     // column direction: two max-only streams per column block
                     m[k][0] = umax3(m[k][0], (unsigned)P[k][0], (unsigned)P[k][2]);
                     m[k][1] = umax3(m[k][1], (unsigned)P[k][1], (unsigned)P[k][3]);
@@ -1659,7 +1668,10 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 }
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
-                    X[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[1], qf[k][1], X[k], 0, 0, 0);
+                    if (KS == 2)
+                        X[k] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[1], qf[k][1], X[k], 0, 0, 0);
+                    else if ((k & 1) == 0)
+                        X[4 + k / 2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f.a[0], qf[4 + k / 2][0], f.cv, 0, 0, 0);
                     if (ISX_PAIR_X & 8) {
                     } else if (k < 2) {
                         w[2 * k] = umax3(w[2 * k], x(5, 2 * k), x(6, 2 * k));
@@ -1750,8 +1762,12 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 // were consumed by this iteration's matrix instructions, the table atomics are only read after the last pass.
                 if (ISX_PAIR_T & 64)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (timing diagnostic: no chunk barrier)
-                else if (c + NBUF - 1 < n_chunks)
-                    asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+                else if (c + NBUF - 1 < n_chunks) {
+                    if (KS == 2)
+                        asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+                }
                 else
                     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef ISX_PAIR_SKEW
@@ -1876,13 +1892,13 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
     if (n_col <= ISX_PAIR_CAP && !(ISX_PAIR_T & 4)) {
         const int gsz = n_col > 16 * WAVES ? 16 : (n_col + WAVES - 1) / WAVES;
         for (int k0 = wv * gsz; k0 < n_col; k0 += WAVES * gsz)
-            good_col += knn2_exact_recount16(desc, nrm, lst + 4 + k0, n_col - k0 < gsz ? n_col - k0 : gsz, it.q_start, it.t_start,
+            good_col += knn2_exact_recount16<KS>(desc, nrm, lst + 4 + k0, n_col - k0 < gsz ? n_col - k0 : gsz, it.q_start, it.t_start,
                                              nt, lane, ratio);
     }
     if (n_row <= ISX_PAIR_CAP && !(ISX_PAIR_T & 4)) {
         const int gsz = n_row > 16 * WAVES ? 16 : (n_row + WAVES - 1) / WAVES;
         for (int k0 = wv * gsz; k0 < n_row; k0 += WAVES * gsz)
-            good_row += knn2_exact_recount16(desc, nrm, lst + 4 + ISX_PAIR_CAP + k0, n_row - k0 < gsz ? n_row - k0 : gsz, it.t_start,
+            good_row += knn2_exact_recount16<KS>(desc, nrm, lst + 4 + ISX_PAIR_CAP + k0, n_row - k0 < gsz ? n_row - k0 : gsz, it.t_start,
                                              it.q_start, nq, lane, ratio);
     }
     if (lane == 0) {
@@ -1900,7 +1916,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
 extern "C" int isx_knn2_l2_count_pairs(const int8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev, int d_pad,
                                        const isx_knn_item *items_dev, int n_items, int max_rows, double ratio,
                                        int32_t *count_out_dev, int flags, void *stream) {
-    ISX_REQUIRE(d_pad == 128, "isx_knn2_l2_count_pairs needs 128-byte rows (got d_pad %d)", d_pad);
+    ISX_REQUIRE(d_pad == 128 || d_pad == 64, "isx_knn2_l2_count_pairs needs 128- or 64-byte rows (got d_pad %d)", d_pad);
     ISX_REQUIRE(n_items >= 0 && max_rows >= 0, "negative size");
     if (n_items == 0 || max_rows == 0) return ISX_OK;
     ISX_REQUIRE(desc_dev && nrm_dev && cin_dev && items_dev && count_out_dev, "null device pointer");
@@ -1909,18 +1925,16 @@ extern "C" int isx_knn2_l2_count_pairs(const int8_t *desc_dev, const int32_t *nr
     // images of up to 4096 rows: the four-group table.  Beyond: two groups per row (a pair whose smaller image has more than
     // 8192 rows or whose larger one more than 16384 comes back as (-1, -1), like any other direction the caller re-runs)
     const bool big = max_rows > ISX_PAIR_MAX_ROWS;
-    const void *fn = big ? (const void *)knn2_pair_filter_kernel<WAVES, 2> : (const void *)knn2_pair_filter_kernel<WAVES, 4>;
-    ISX_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ISX_PAIR_LDS));
+    typedef void (*pair_fn)(const int8_t *, const int32_t *, const int32_t *, const isx_knn_item *, int, double, int32_t *, int);
+    const pair_fn fn = d_pad == 128 ? (big ? knn2_pair_filter_kernel<WAVES, 2, 2> : knn2_pair_filter_kernel<WAVES, 4, 2>)
+                                    : (big ? knn2_pair_filter_kernel<WAVES, 2, 1> : knn2_pair_filter_kernel<WAVES, 4, 1>);
+    ISX_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, ISX_PAIR_LDS));
     const int per = isx_items_per_launch(1, 64 * WAVES);
     hipStream_t st = (hipStream_t)stream;
     for (int off = 0; off < n_items; off += per) {
         const int n = n_items - off < per ? n_items - off : per;
-        if (big)
-            hipLaunchKernelGGL((knn2_pair_filter_kernel<WAVES, 2>), dim3((unsigned)n), dim3(64 * WAVES), ISX_PAIR_LDS, st, desc_dev,
-                               nrm_dev, cin_dev, items_dev + off, n, ratio, count_out_dev + 2 * (int64_t)off, flags);
-        else
-            hipLaunchKernelGGL((knn2_pair_filter_kernel<WAVES, 4>), dim3((unsigned)n), dim3(64 * WAVES), ISX_PAIR_LDS, st, desc_dev,
-                               nrm_dev, cin_dev, items_dev + off, n, ratio, count_out_dev + 2 * (int64_t)off, flags);
+        hipLaunchKernelGGL(fn, dim3((unsigned)n), dim3(64 * WAVES), ISX_PAIR_LDS, st, desc_dev, nrm_dev, cin_dev, items_dev + off, n,
+                           ratio, count_out_dev + 2 * (int64_t)off, flags);
     }
     return isx_launch_status("knn2_pair_filter_kernel");
 }

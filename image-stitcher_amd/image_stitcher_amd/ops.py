@@ -162,7 +162,7 @@ PAIR_MIN_ITEMS = 512   # below this many pairs the one-workgroup-per-pair kernel
 def pairs_kernel_applies(P, pair_items):
     """True when the both-directions kernel (isx_knn2_l2_count_pairs) can and should run this pair list."""
     it = np.asarray(pair_items).reshape(-1, 4)
-    if P.wide or P.d_pad != 128 or len(it) < PAIR_MIN_ITEMS:
+    if P.wide or P.d_pad not in (64, 128) or len(it) < PAIR_MIN_ITEMS:
         return False
     lo, hi = np.minimum(it[:, 1], it[:, 3]), np.maximum(it[:, 1], it[:, 3])
     if int(hi.max()) <= PAIR_MAX_ROWS:

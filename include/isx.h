@@ -119,7 +119,7 @@ int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, cons
                             int32_t *count_out_dev, int flags, void *stream);
 
 /* Both directions of UNORDERED image pairs from one distance matrix (round 3): reference stitcher.py:285-296 visits
- * (i, j) and (j, i); this entry point forms the 128-byte-row products of a pair once (half the matrix instructions of
+ * (i, j) and (j, i); this entry point forms the products of a pair of 128- or 64-byte-row images once (half the matrix instructions of
  * two isx_knn2_l2_count_items items) and settles almost every query with a max-only filter that proves "not a good
  * match"; the few candidates are recounted exactly in the kernel.  One work item = one pair: {q_start, nq} = image j,
  * {t_start, nt} = image i.
@@ -128,7 +128,7 @@ int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, cons
  *   -1 = that direction has more than 128 candidates (the images overlap), or the other direction of the pair had and
  *        the kernel left the pair early: the caller runs it as an item of isx_knn2_l2_count_items.  Every other value
  *        is the exact count (same as isx_knn2_l2_count_items).
- * count_out_dev need not be zeroed.  d_pad must be 128.  max_rows = max over items of nq and nt: up to 4096 the kernel keeps
+ * count_out_dev need not be zeroed.  d_pad must be 128 (SIFT) or 64 (AKAZE's 61 bytes, padded).  max_rows = max over items of nq and nt: up to 4096 the kernel keeps
  * four group maxima per row; beyond, two (a few more candidates are recounted), the smaller image of a pair is made the train
  * side, and a pair whose smaller image has more than 8192 rows or whose larger one more than 16384 comes back as (-1, -1).  Rows sorted
  * by nrm inside each image keep the candidate lists short (counts do not depend on the row order); any order is exact.

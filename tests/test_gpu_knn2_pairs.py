@@ -104,9 +104,9 @@ def test_sorted_rows_leave_counts_unchanged_and_shrink_the_candidate_lists(cuda)
 def test_pairs_kernel_refuses_what_it_cannot_run(cuda):
     from image_stitcher_amd import ops
     from image_stitcher_amd._lib import IsxError
-    des = _ragged_set(1, [300, 10], d=64)
+    des = _ragged_set(1, [300, 10], d=32)
     P = ops.prepare_descriptors(des)
-    with pytest.raises(IsxError):  # 64-byte rows
+    with pytest.raises(IsxError):  # 32-byte rows
         ops.knn2_l2_pairs(P, np.array([[0, 300, 300, 10]], np.int32), 0.65)
     assert not ops.pairs_kernel_applies(P, np.array([[0, 300, 300, 10]] * 5000, np.int32))
     # images the two-group table cannot hold either: more than half of the pairs -> not worth the launch
@@ -136,3 +136,22 @@ def test_pairs_kernel_images_beyond_4096_rows(cuda, orc, sort_rows):
     got = ops.knn2_l2_pairs(P, items, 0.8, stats=stt).cpu().numpy()
     assert np.array_equal(got, want), (got.tolist(), want.tolist())
     assert stt["overflow_directions"] >= 2  # at least the 8300 x 9000 pair
+
+
+@pytest.mark.parametrize("d", [61, 64])
+def test_pairs_kernel_64_byte_rows(cuda, orc, d):
+    """AKAZE-width descriptors (61 bytes, padded to 64-byte rows; 64 as well): one matrix instruction per tile and column
+    block, the same filter and recount.  Ragged sizes incl. images beyond 4096 rows, sorted rows, against the oracle."""
+    from image_stitcher_amd import ops, pairs as prs
+    sizes = [1, 17, 128, 129, 1000, 1024, 1025, 2500, 4096, 5000, 640]
+    des = _ragged_set(21, sizes, d=d)
+    P = ops.sort_rows_by_norm(ops.prepare_descriptors(des))
+    assert P.d_pad == 64
+    all_pairs = prs.unordered_pairs(len(sizes))
+    items = prs.pair_items(all_pairs, np.asarray(P.starts), np.asarray(P.counts))
+    want = _oracle_counts(orc, des, all_pairs, 0.8)
+    assert want.max() > 50 and (want == 0).any()
+    got = ops.knn2_l2_pairs(P, items, 0.8).cpu().numpy()
+    assert np.array_equal(got, want), np.argwhere(got != want)[:10]
+    got1 = ops.knn2_l2_pairs(P, items, 0.8, flags=1).cpu().numpy()
+    assert np.array_equal(got1, want)

@@ -1,6 +1,6 @@
 """Randomised parity of isx_knn2_l2_count_pairs (both directions of a pair from one distance matrix: max-only filter, exact
 recount, overflow to the directed kernel, early exit) against the oracle's knnMatch + ratio loop (reference
-stitcher.py:285-296) and against the directed count kernel: ragged 128-d image sets up to 4096 rows (one to four passes, partly
+stitcher.py:285-296) and against the directed count kernel: ragged 128-d (and 64- / 61-d) image sets up to 4096 rows (one to four passes, partly
 filled last classes), value ranges that force ties, planted near-duplicates from a handful to most of an image (candidate lists
 from empty to overflowing, in one direction or both), sorted and unsorted rows, several ratios, the every-query-is-a-candidate
 hook.   usage: python3 tools/fuzz_pairs.py [cases=40] [seed0]   (exit status 1 on any mismatch)"""
@@ -14,7 +14,7 @@ from oracle import orc
 
 def one_case(seed):
     rng = np.random.default_rng(seed)
-    d = 128
+    d = int(rng.choice([128, 128, 64, 61]))
     hi = int(rng.choice([4, 60, 150, 256]))
     n_img = int(rng.integers(2, 6))
     pick = lambda: int(rng.choice([1, 2, 16, 127, 128, 129, 1023, 1024, 1025, 2048, 2049, 3000, 4095, 4096,

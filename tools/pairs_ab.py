@@ -1,5 +1,5 @@
 """A/B of the both-directions pair kernel (isx_knn2_l2_count_pairs + overflow stage) against the two-pass directed kernel on
-an all-pairs set: equal counts, ms per pass.  usage: python3 tools/pairs_ab.py [n_images=128] [sort=1] [kp=4096]   (kp > 4096: the kernel's two-group table)"""
+an all-pairs set: equal counts, ms per pass.  usage: python3 tools/pairs_ab.py [n_images=128] [sort=1] [kp=4096] [d=128]   (kp > 4096: the kernel's two-group table; d = 64 or 61: 64-byte rows)"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "image-stitcher_amd"))
 import numpy as np, torch
@@ -8,7 +8,7 @@ from image_stitcher_amd.synthetic import overlapping_crops_descriptors
 
 n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 do_sort = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-kp, d = (int(sys.argv[3]) if len(sys.argv) > 3 else 4096), 128
+kp, d = (int(sys.argv[3]) if len(sys.argv) > 3 else 4096), (int(sys.argv[4]) if len(sys.argv) > 4 else 128)
 des, _ = overlapping_crops_descriptors(seed=1234, n_scenes=max(1, n_img // 64), imgs_per_scene=min(64, n_img), kp=kp, step=kp * 448 // 4096, d=d)
 n_img = des.shape[0]
 src = torch.from_numpy(des.reshape(-1, d)).cuda()
