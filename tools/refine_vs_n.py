@@ -39,3 +39,11 @@ for refit, iters in ((True, 10), (True, 0), (False, 10), (False, 0)):
         _, info = ops.ransac_refine(Md, sd, dd, True, 5.0, refit=refit, max_iters=iters)
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
     print(f"homography n=500 refit={refit} lm_iters={iters}: {min(ts):6.1f} us  info={info.cpu().tolist()}", flush=True)
+
+for iters in (0, 1, 2, 3, 5, 10):
+    ts = []
+    for rep in range(6):
+        Md = best.clone(); torch.cuda.synchronize(); e0.record()
+        ops.ransac_refine(Md, sd, dd, True, 5.0, refit=True, max_iters=iters)
+        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
+    print(f"homography n=500 refit=True lm_iters={iters:2d}: {min(ts):6.1f} us", flush=True)
