@@ -79,3 +79,43 @@ def test_pair_sharding_covers_every_pair_once():
     assert all(0 < b - a <= 2 for a, b in q) and len(q) == 9 + 8
     it = prs.directed_items(p[:3], np.arange(37) * 10, np.full(37, 10))
     assert it.shape == (6, 4) and (it[0] == [0, 10, 10, 10]).all() and (it[1] == [10, 10, 0, 10]).all()
+
+
+def _prepared_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from image_stitcher_amd import ops, pairs as prs
+        per, kp, d_pad = 3, 50, 128
+        n = per * world
+        rng = np.random.default_rng(100 + rank)
+        rows = per * kp
+        # a rank's PREPARED shard (on the GPU box: ops.prepare_descriptor_tensor + sort_rows_by_norm of its own images)
+        Pl = ops.PreparedDescriptors(torch.from_numpy(rng.integers(-128, 128, (rows, d_pad), dtype=np.int8)),
+                                     torch.from_numpy(rng.integers(0, 2 ** 31 - 1, (rows,)).astype(np.int32)),
+                                     torch.from_numpy(rng.integers(0, 2 ** 22, (rows,)).astype(np.int32)),
+                                     torch.from_numpy(rng.integers(-2 ** 22, 2 ** 22, (rows,)).astype(np.int32)),
+                                     np.arange(per) * kp, np.full(per, kp), 128, d_pad, 12345, False)
+        starts, counts = np.arange(n) * kp, np.full(n, kp)
+        P = prs.all_gather_prepared(Pl, starts, counts)
+        assert P.desc.shape == (n * kp, d_pad) and P.desc.dtype == torch.int8 and P.desc.is_contiguous()
+        assert P.nrm.shape == (n * kp,) and P.nrm.dtype == torch.int32
+        np.savez(out_path + f".{rank}.npz", desc=Pl.desc.numpy(), cbase=Pl.cbase.numpy(), nrm=Pl.nrm.numpy(), cin=Pl.cin.numpy(),
+                 g_desc=P.desc.numpy(), g_cbase=P.cbase.numpy(), g_nrm=P.nrm.numpy(), g_cin=P.cin.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_gather_prepared_concatenates_the_ranks_fields(tmp_path, world):
+    """pairs.all_gather_prepared (bench.py's collective on the way in since round 3): the four fields of every rank's prepared
+    shard come back concatenated in rank order, on every rank, from ONE uint8 all_gather."""
+    out = str(tmp_path / "prep")
+    mp.spawn(_prepared_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    parts = [np.load(out + f".{r}.npz") for r in range(world)]
+    for f in ("desc", "cbase", "nrm", "cin"):
+        want = np.concatenate([p[f] for p in parts])
+        for p in parts:
+            assert np.array_equal(p["g_" + f], want), f
