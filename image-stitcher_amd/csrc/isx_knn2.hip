@@ -1557,7 +1557,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
         }
         f.a[0] = *(const v4i *)(base + fo0 + t * (16 * DP));
         if (KS == 2) f.a[1] = *(const v4i *)(base + fo1 + t * (16 * DP));
-        f.cv = *(const v4i *)(base + foc + t * 64);
+        if (!(ISX_PAIR_X & 256) || t == 0) f.cv = *(const v4i *)(base + foc + t * 64); // (256: timing diagnostic, one tile's norms for all)
     };
     // this lane's slot of the row table in tile 0 of chunk 0: row 4g + (lane & 3), group (lane >> 2) & 3
     // as an LDS byte address, one tile back (the dummy tile): the fold adds (tile + 1) * 256 + 16 r as an immediate
