@@ -155,3 +155,21 @@ def test_pairs_kernel_64_byte_rows(cuda, orc, d):
     assert np.array_equal(got, want), np.argwhere(got != want)[:10]
     got1 = ops.knn2_l2_pairs(P, items, 0.8, flags=1).cpu().numpy()
     assert np.array_equal(got1, want)
+
+
+def test_pairs_kernel_empty_images(cuda, orc):
+    """Images without keypoints (update_all_keypoints_and_descriptors drops them, but a caller of the C ABI may pass them): every
+    direction that involves one counts 0, with both tables, and the other pairs of the launch are unaffected."""
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(0)
+    des = [rng.integers(0, 200, (n, 128), dtype=np.uint8) if n else None for n in (100, 0, 300, 5000, 0)]
+    des[2][:60] = np.clip(des[0][:60].astype(np.int16) + rng.integers(-1, 2, (60, 128)), 0, 255).astype(np.uint8)
+    P = ops.prepare_descriptors(des)
+    st, ct = np.asarray(P.starts), np.asarray(P.counts)
+    for pairs in ([(0, 1), (1, 0), (1, 4), (0, 2), (2, 1)], [(3, 1), (1, 3), (3, 0), (4, 3), (2, 0)]):
+        items = np.array([(st[i], ct[i], st[j], ct[j]) for i, j in pairs], np.int32)
+        got = ops.knn2_l2_pairs(P, items, 0.8).cpu().numpy()
+        want = np.array([[0 if des[i] is None or des[j] is None else orc.match_count(des[i], des[j], 0.8),
+                          0 if des[i] is None or des[j] is None else orc.match_count(des[j], des[i], 0.8)] for i, j in pairs], np.int32)
+        assert np.array_equal(got, want), (got.tolist(), want.tolist())
+    assert want.max() >= 50
