@@ -143,7 +143,7 @@ def test_config1_full_size_1080p_frames(cuda, orc, tmp_path, type_, blender):
 def test_config4_scale_all_pairs_4096_images(cuda, orc):
     """configs[4] at its stated size: one pass of the all-pairs matcher over 4096 images x 4096 keypoints x 128-d
     (2 GiB of descriptors generated on the device, 8,386,560 unordered pairs, 16.8 M directed items: five launches,
-    HIP forms gridDim*blockDim in 32 bits; about 23 s of kernel).  The oracle would need days for all of it, so
+    HIP forms gridDim*blockDim in 32 bits; about 23 s of kernel on the directed kernel and 13 s more on the pair kernel).  The oracle would need days for all of it, so
     (1) 36 directed items of this pass -- union edges, items within +-2 of min_match_count, random ones -- are
     recounted with the oracle (knnMatch float32 + ratio loop, reference stitcher.py:285-296) on the downloaded
     images, and (2) the whole count matrix is checked through the size-independent properties of
@@ -164,6 +164,11 @@ def test_config4_scale_all_pairs_4096_images(cuda, orc):
     P = ops.prepare_descriptor_tensor(des.reshape(-1, d), starts, counts)
     c0 = ops.knn2_l2_items(P, items, 0.65).cpu().numpy().reshape(-1, 2)
     del items
+    # the same pass on the kernel the product runs since round 3 (both directions of a pair from one distance matrix, rows
+    # sorted by norm): all 16.8 M directions equal the directed kernel's, which the oracle sample below pins
+    cp = ops.knn2_l2_pairs(ops.sort_rows_by_norm(P), prs.pair_items(all_pairs, starts, counts), 0.65).cpu().numpy()
+    assert np.array_equal(cp, c0)
+    del cp
     sample, _ = oracle_sample_of_directed_items(c0, all_pairs, 36, 5, np.random.default_rng(5))
     assert len(sample) >= 30
     assert_counts_match_oracle(orc, lambda i: des[i].cpu().numpy(), c0, all_pairs, sample, 0.65, nthreads=16)

@@ -139,6 +139,17 @@ def test_full_size_all_pairs_properties(cuda, orc):
         torch.cuda.synchronize()
         return c.cpu().numpy()
     c0 = run(des, items).reshape(-1, 2)
+    # the kernel the product and bench.py run on this set since round 3 -- one distance matrix per unordered pair
+    # (isx_knn2_l2_count_pairs, rows sorted by norm, overflowing directions re-run on the directed kernel): every one of the
+    # 261,632 directions must equal the directed kernel's count, which the oracle sample below pins
+    Pp = ops.sort_rows_by_norm(ops.prepare_descriptor_tensor(torch.from_numpy(des.reshape(-1, d)).cuda(), starts, counts))
+    pitems = prs.pair_items(all_pairs, starts, counts)
+    assert ops.pairs_kernel_applies(Pp, pitems)
+    st = {}
+    cp = ops.knn2_l2_pairs(Pp, pitems, 0.65, stats=st).cpu().numpy()
+    assert np.array_equal(cp, c0), np.argwhere(cp != c0)[:10]
+    assert 0 < st["overflow_directions"] < 0.05 * c0.size
+    del Pp
     # oracle sample of THIS launch
     sample, n_near = oracle_sample_of_directed_items(c0, all_pairs, 48, 5, np.random.default_rng(11))
     assert len(sample) >= 40
