@@ -201,6 +201,38 @@ def test_get_collections_small(cuda, orc, world):
     assert len(st.des) == 7 and len(st.images) == 7
 
 
+@pytest.mark.parametrize("width,dtype", [(128, np.float32), (61, np.uint8)])
+def test_get_collections_through_the_pair_kernel(cuda, orc, width, dtype):
+    """ArbitraryStitcher.get_collections (stitcher.py:280-304) on a set large enough (40 images, 780 pairs) to take the
+    product's round-3 route: rows sorted by norm, isx_knn2_l2_count_pairs, overflowing directions re-run on the directed
+    kernel.  Integer-valued float32 128-d descriptors as cv2.SIFT returns them, and 61-byte AKAZE-width ones (64-byte rows).
+    Every pair's two counts and the components against the oracle's double loop."""
+    from image_stitcher_amd import ArbitraryStitcher, ops, pairs as prs
+    from image_stitcher_amd.synthetic import overlapping_crops_descriptors
+    des, scene_of = overlapping_crops_descriptors(seed=31, n_scenes=4, imgs_per_scene=10, kp=700, step=120, d=width)
+    arrays = [d.astype(dtype) for d in des]
+
+    class Stub:
+        def __init__(self):
+            self.k = 0
+
+        def detectAndCompute(self, image, mask=None):
+            d = arrays[self.k % len(arrays)]
+            self.k += 1
+            return [None] * len(d), d
+    n = len(arrays)
+    st = ArbitraryStitcher(images=[np.zeros((8, 8, 3), np.uint8)] * n, with_tqdm=False, log_level=3, detector=Stub())
+    cols = st.get_collections()
+    pairs, counts = st.good_counts
+    assert len(pairs) == n * (n - 1) // 2 >= ops.PAIR_MIN_ITEMS
+    want = np.array([[orc.match_count(arrays[i], arrays[j], 0.65, nthreads=8), orc.match_count(arrays[j], arrays[i], 0.65, nthreads=8)]
+                     for i, j in pairs], np.int32)
+    assert np.array_equal(np.asarray(counts), want), np.argwhere(np.asarray(counts) != want)[:10]
+    assert want.max() > 100
+    exp, _ = prs.components_from_counts(n, pairs, want[:, 0], want[:, 1], 5)
+    assert cols == exp and sorted(map(sorted, cols)) == sorted(sorted(np.nonzero(scene_of == s)[0].tolist()) for s in range(4))
+
+
 def test_no_gpu_free_cpu_path(cuda):
     """The product never falls back to the CPU: CPU tensors are rejected loudly."""
     import torch
