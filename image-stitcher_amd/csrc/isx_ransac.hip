@@ -609,7 +609,27 @@ struct RefineShared {
     double JtJ[64], Ab[72], v[8], d[8], x[8], xd[8], D[8];
     double S, Sd, lambda, lc;
     int proceed;
+    double red[45 * 65], sum[48]; // wave_sums' transposed partials (rows padded to 65: lanes then read different banks) and totals
 };
+
+// Totals over the wave of N per-lane sums at once (N <= 45), left in sh.sum[0..N): every lane writes its N partials to LDS,
+// lane t adds up column t.  Doing them one by one costs a DPP + v_readlane butterfly each (~35 instructions): the 45 sums of a
+// homography's normal equations were ~3.5 us of every LM iteration, the 15 of the similarity's ~1 us.  The order of the
+// additions is lane 0, 1, ... 63 (the butterfly's was a tree): same sums to rounding.
+template <int N>
+__device__ __forceinline__ void wave_sums(RefineShared &sh, const double (&acc)[N], int lane) {
+    static_assert(N <= 45, "sh.red holds 45 rows");
+#pragma unroll
+    for (int i = 0; i < N; i++) sh.red[i * 65 + lane] = acc[i];
+    __syncthreads();
+    if (lane < N) {
+        double t = 0;
+#pragma unroll 8
+        for (int l = 0; l < 64; l++) t += sh.red[lane * 65 + l];
+        sh.sum[lane] = t;
+    }
+    __syncthreads();
+}
 
 // accumulate J^T J, J^T r and |r|^2 over the inliers at parameters sh.x
 template <int NP>
@@ -639,8 +659,7 @@ __device__ __forceinline__ void lm_normal_equations(RefineShared &sh, const floa
         acc[NU + NP] += r0 * r0 + r1 * r1;
         ri = fmax(ri, fmax(fabs(r0), fabs(r1)));
     }
-#pragma unroll
-    for (int i = 0; i < NU + NP + 1; i++) acc[i] = wsum(acc[i]);
+    wave_sums<NU + NP + 1>(sh, acc, lane);
     rinf = wmax(ri);
     if (lane == 0) {
         int u = 0;
@@ -648,14 +667,15 @@ __device__ __forceinline__ void lm_normal_equations(RefineShared &sh, const floa
         for (int a = 0; a < NP; a++) {
 #pragma unroll
             for (int b = a; b < NP; b++) {
-                sh.JtJ[a * NP + b] = acc[u];
-                sh.JtJ[b * NP + a] = acc[u];
+                const double t = sh.sum[u];
+                sh.JtJ[a * NP + b] = t;
+                sh.JtJ[b * NP + a] = t;
                 u++;
             }
         }
 #pragma unroll
-        for (int a = 0; a < NP; a++) sh.v[a] = acc[NU + a];
-        sh.S = acc[NU + NP];
+        for (int a = 0; a < NP; a++) sh.v[a] = sh.sum[NU + a];
+        sh.S = sh.sum[NU + NP];
     }
     __syncthreads();
 }
@@ -920,8 +940,9 @@ __global__ void __launch_bounds__(64) ransac_refine_kernel(int model, double *__
                         for (int k = j; k < 9; k++) acc[u++] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
                     }
                 }
+                wave_sums<45>(sh, acc, lane);
 #pragma unroll
-                for (int i = 0; i < 45; i++) acc[i] = wsum(acc[i]);
+                for (int i = 0; i < 45; i++) acc[i] = sh.sum[i]; // (every lane: smallest_eigvec9 runs redundantly)
                 double hv[9];
                 const bool quick = smallest_eigvec9(acc, hv); // (wave-uniform: every lane holds the same sums)
                 if (!quick) {

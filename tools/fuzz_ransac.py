@@ -1,7 +1,7 @@
 """Randomised parity of the robust-transform stage (get_transform, reference stitcher.py:135-141) against the oracle's sequential
 RANSAC (oracle/orc_ransac.c): random point counts (4 .. 3000), outlier fractions, noise levels (exact data included: the refit's
 LtL is then singular), perspective strengths; both models.  Bar: the same inlier mask, M within 1e-3 px RMS over the inliers --
-on sets of at least 12 points spread over the frame.  Homographies from 5-8 points (up to 0.06 px apart), clustered (sigma 60 x 40 px) and band-shaped (sigma 3 px across) sets are run and REPORTED
+on sets with at least 12 inliers spread over the frame.  Homographies from fewer inliers (up to 0.6 px apart), clustered (sigma 60 x 40 px) and band-shaped (sigma 3 px across) sets are run and REPORTED
 but not gated for the homography's M: it is barely determined there, Levenberg-Marquardt walks a flat valley and the two
 implementations (wave-parallel sums here, sequential ones in the oracle) stop after cv's ten iterations apart -- by up to 0.5 px on
 the clusters, by pixels on a 3-px band (a nearly collinear set determines no homography); the inlier masks must still agree.   usage: python3 tools/fuzz_ransac.py [cases=100] [seed0]"""
@@ -54,7 +54,7 @@ def main(N, seed0=310000):
                 a, b = apply_m(np.asarray(M), src[inl].astype(np.float64)), apply_m(np.asarray(Mo), src[inl].astype(np.float64))
                 rms = float(np.sqrt(((a - b) ** 2).sum(1).mean()))
                 ok = rms < 1e-3
-                if not ok and persp and (shape != "uniform" or n < 12):
+                if not ok and persp and (shape != "uniform" or int(inl.sum()) < 12):
                     soft += 1
                     worst = max(worst, rms)
                     ok = True
