@@ -10,7 +10,8 @@ SIFT-like keypoints (integer-valued 128-d descriptors, 8 planted scenes of 64 ov
 SURVEY.md section 8d).  One STEP = one full all-pairs pass: descriptor preparation (+ rows sorted by norm) of the
 rank's own images -> [all_gather of the prepared rows over RCCL when N>1] -> fused kNN-2 + Lowe-ratio
 counts of both directions of this rank's share of the 130,816 unordered pairs (one launch over all pairs,
-one over the overlapping ones) -> gather of the int32 good-match counts -> host union-find on rank 0.  Inputs (the raw uint8 descriptor shard) are resident in HBM
+one over the overlapping ones) -> gather of the int32 good-match counts -> host union-find on rank 0 (deferred by one step:
+it runs while the next step's kernel is on the GPU; the last one before the closing fence).  Inputs (the raw uint8 descriptor shard) are resident in HBM
 when the timed region starts.  The pair space is fixed and split over the ranks => "scaling":
 "strong".
 
@@ -342,6 +343,21 @@ def main():
     kernel_ms, parts = [], []
     result = {}
 
+    # rank 0's host part of a step (counts read-back + union-find) is deferred by one step in the timed loop: the counts go to
+    # pinned memory by an asynchronous copy behind the step's kernels, and the union-find runs while the NEXT step's pair kernel
+    # is on the GPU (ops.knn2_l2_pairs(while_running=...)); the last step's runs before the closing fence, inside the timed region
+    host_bufs = [torch.empty((len(all_pairs), 2), dtype=torch.int32).pin_memory() for _ in range(2)] if rank == 0 else None
+    pending, step_no = [None], [0]
+
+    def finish_pending():
+        if pending[0] is not None:
+            hb, done = pending[0]
+            pending[0] = None
+            done.synchronize()
+            h = hb.numpy()
+            comps, _ = prs.components_from_counts(n, all_pairs, h[:, 0], h[:, 1], min_match)
+            result["comps"], result["counts"] = comps, h.copy()
+
     def step(record):
         if record:
             marks[0].record()
@@ -359,7 +375,7 @@ def main():
         if two_pass:
             c = ops.knn2_l2_items(P, None, ratio, plan=plan, events=ev if record else None)
         else:
-            c = ops.knn2_l2_pairs(P, None, ratio, plan=plan, events=ev if record else None, stats=stage)
+            c = ops.knn2_l2_pairs(P, None, ratio, plan=plan, events=ev if record else None, stats=stage, while_running=finish_pending)
         if record:
             marks[2].record()
         allc = prs.gather_counts(c.view(-1, 2), len(all_pairs), rank, world)
@@ -368,9 +384,15 @@ def main():
             torch.cuda.synchronize()  # (instrumented steps only: the host figure below must not include the wait for the GPU)
         t_host = time.perf_counter()
         if rank == 0:
-            h = allc.cpu().numpy()
-            comps, _ = prs.components_from_counts(n, all_pairs, h[:, 0], h[:, 1], min_match)
-            result["comps"], result["counts"] = comps, h
+            finish_pending()  # (two-pass path, or nothing left to do)
+            hb = host_bufs[step_no[0] % 2]
+            step_no[0] += 1
+            hb.copy_(allc, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            pending[0] = (hb, done)
+            if record:
+                finish_pending()  # instrumented steps: in line, so that host_ms_rank0 is the plain cost
         if record:
             torch.cuda.synchronize()
             host_ms = (time.perf_counter() - t_host) * 1e3
@@ -382,6 +404,7 @@ def main():
                           marks[2].elapsed_time(marks[3]), host_ms))
 
     def fence():
+        finish_pending()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

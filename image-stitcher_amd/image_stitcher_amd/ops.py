@@ -172,13 +172,14 @@ def pairs_kernel_applies(P, pair_items):
     return float(np.mean((lo <= PAIR_BIG_TRAIN) & (hi <= PAIR_BIG_QUERY))) >= 0.5
 
 
-def knn2_l2_pairs(P, pair_items, ratio, plan=None, events=None, flags=0, stats=None):
+def knn2_l2_pairs(P, pair_items, ratio, plan=None, events=None, flags=0, stats=None, while_running=None):
     """Good-match counts of both directions of unordered image pairs (the loop body of get_collections, reference
     stitcher.py:285-296) from ONE distance matrix per pair: isx_knn2_l2_count_pairs, then isx_knn2_l2_count_items for
     the directions it reports as overflowing (overlapping images, more than 128 candidate queries).
     pair_items: (n,4) int32 rows (q_start, nq, t_start, nt).  Returns (n,2) int32 on the device:
     [:,0] = len(good) of (query = the q image, train = the t image), [:,1] = the other direction.  Exact counts.
-    stats: optional dict, receives 'overflow_directions'."""
+    stats: optional dict, receives 'overflow_directions'.  while_running: optional callable, called once after the first launch
+    is queued and before this function waits for it (host work that should overlap the kernel)."""
     L = _lib.lib()
     dev = P.device
     with torch.cuda.device(dev):
@@ -195,6 +196,8 @@ def knn2_l2_pairs(P, pair_items, ratio, plan=None, events=None, flags=0, stats=N
         check(L.isx_knn2_l2_count_pairs(_ptr(P.desc), _ptr(P.nrm), _ptr(P.cin), P.d_pad, _ptr(items_dev), m, max_rows,
                                         float(ratio), _ptr(counts), int(flags), _stream()))
         flat = counts.view(-1)
+        if while_running is not None:
+            while_running()
         over = torch.nonzero(flat < 0).view(-1)          # (host sync: the length of the second stage's item list)
         n_over = int(over.shape[0])
         if stats is not None:
