@@ -1559,10 +1559,10 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
         if (KS == 2) f.a[1] = *(const v4i *)(base + fo1 + t * (16 * DP));
         if (!(ISX_PAIR_X & 256) || t == 0) f.cv = *(const v4i *)(base + foc + t * 64); // (256: timing diagnostic, one tile's norms for all)
     };
-    // this lane's slot of the row table in tile 0 of chunk 0: row 4g + (lane & 3), group (lane >> 2) & 3
+    // this lane's slot of the row table in tile 0 of chunk 0: row 4g + its quad (lane >> 2) & 3, group = its position lane & 3
     // as an LDS byte address, one tile back (the dummy tile): the fold adds (tile + 1) * 256 + 16 r as an immediate
-    // (NG == 2: group (lane >> 3) & 1, written by the lanes of the even quads only)
-    const unsigned row_slot_lds = smem_lds + NBUF * BUF + 256 - 16 * ROWB + (4 * g + (lane & 3)) * ROWB + (NG == 4 ? (lane >> 2) & 3 : (lane >> 3) & 1) * 4;
+    // (NG == 2: group (lane >> 1) & 1, written by the lanes at even positions only)
+    const unsigned row_slot_lds = smem_lds + NBUF * BUF + 256 - 16 * ROWB + (4 * g + ((lane >> 2) & 3)) * ROWB + (NG == 4 ? lane & 3 : (lane >> 1) & 1) * 4;
 
     v4i qf[NCB][2];
     unsigned phantom = 0; // bit cb: this lane's column of block cb is beyond nq
@@ -1682,46 +1682,42 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                         w[r] = w[r] > a7 ? w[r] : a7;
                         w[r + 1] = w[r + 1] > b7 ? w[r + 1] : b7;
                     } else if (k == 4 && !(ISX_PAIR_X & 4)) {
-                        // 16 -> 4 lanes AND 4 registers -> 1: after the two quad steps lane j of a quad holds row register j's
-                        // maximum over the quad (a butterfly: pair maxima, select by lane bit 0, pair maxima, select by lane
-                        // bit 1) -- 9 vector ops, and then ONE tag op and ONE ds_max_u32 from all 64 lanes instead of four
-                        // of each from the quad leaders
-                        asm volatile("v_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                     "v_max_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                     "v_max_u32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                     "v_max_u32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                                     "v_cndmask_b32_e64 %0, %0, %1, %4\n\t"
-                                     "v_cndmask_b32_e64 %2, %2, %3, %4"
-                                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])
-                                     : "s"(0xAAAAAAAAAAAAAAAAull));
+                        // 16 lanes x 4 registers -> 1 register, SIX ops: a reduce-scatter over the four quads of a row.  The
+                        // groups of the table are the four lane positions inside a quad; quad q ends up with row register q's
+                        // maxima over the four quads.  DPP's bank mask (one bit per quad) writes only the quads that keep the
+                        // other register of a pair, so no select is needed: quads {0, 2} keep w0 / w2, quads {1, 3} w1 / w3, each
+                        // combined with its neighbour quad (row_ror:12 reads quad q + 1, row_ror:4 quad q - 1) ...
+                        asm volatile("v_max_u32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_max_u32_dpp %2, %2, %2 row_ror:12 row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_max_u32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa\n\t"
+                                     "v_max_u32_dpp %2, %3, %3 row_ror:4 row_mask:0xf bank_mask:0xa"
+                                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
                     } else if (k == 5 && !(ISX_PAIR_X & 4)) {
-                        asm volatile("v_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                                     "v_max_u32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                                     "v_cndmask_b32_e64 %0, %0, %1, %2"
-                                     : "+v"(w[0]), "+v"(w[2])
-                                     : "s"(0xCCCCCCCCCCCCCCCCull));
+                        // ... then the quads two apart: quads {0, 1} finish w0 / w1, quads {2, 3} take w2 / w3
+                        asm volatile("v_max_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                                     "v_max_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc"
+                                     : "+v"(w[0]), "+v"(w[2]));
                     } else if (k == 6 && (ISX_PAIR_X & 2)) {
                         asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]));
                     } else if (k == 6 && NG == 4) {
-                        // the class's correction and tag, then the LDS max into the row table: lane -> (row 4g + (lane & 3),
-                        // group (lane >> 2) & 3), 64 consecutive words per tile
+                        // the class's correction and tag, then the LDS max into the row table: lane -> (row 4g + its quad,
+                        // group = its position in the quad), 64 consecutive words per tile
                         asm volatile("v_lshl_add_u32 %0, %0, 5, %2\n\t"
                                      "ds_max_u32 %1, %0 offset:%3"
                                      : "+v"(w[0])
                                      : "v"(slot_addr), "s"(kcl), "n"(TB)
                                      : "memory");
                     } else if (k == 6) {
-                        // two groups per row: the even quads take their right-hand neighbours' maxima (lane + 4 holds the same
-                        // row) and write, 32 words per tile
+                        // two groups per row: the even positions take their odd neighbours' maxima and write, 32 words per tile
                         unsigned long long keep;
-                        asm volatile("v_max_u32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                        asm volatile("v_max_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                                      "v_lshl_add_u32 %1, %1, 7, %3\n\t"
                                      "s_mov_b64 %0, exec\n\t"
                                      "s_mov_b64 exec, %4\n\t"
                                      "ds_max_u32 %2, %1 offset:%5\n\t"
                                      "s_mov_b64 exec, %0"
                                      : "=&s"(keep), "+v"(w[0])
-                                     : "v"(slot_addr), "s"(kcl), "s"(0x0F0F0F0F0F0F0F0Full), "n"(TB)
+                                     : "v"(slot_addr), "s"(kcl), "s"(0x5555555555555555ull), "n"(TB)
                                      : "memory");
                     }
                     if (!(ISX_PAIR_X & 1)) __builtin_amdgcn_sched_barrier(0);
