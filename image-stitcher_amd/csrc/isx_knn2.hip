@@ -1307,16 +1307,17 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
 //     H1      = the largest group maximum          = the query's best value, exactly
 //     H2lo    = the second largest group maximum  <= its true second best value (two distinct candidates reach it)
 //     good needs d1 < ratio * d2; with d2 <= d(H2lo) the test can only get harder, so "not good at (d(H1), d(H2lo))"
-//     is final.  Whoever passes is a CANDIDATE: up to ISX_PAIR_CAP per direction are recounted exactly by a wave
-//     (knn2_exact_scan); a direction with more (overlapping images) is reported as -1 and the caller runs it on the
-//     two-pass kernel.  Counts are therefore the exact counts, bit for bit, whatever the filter lets through.
+//     is final.  Whoever passes is a CANDIDATE: up to ISX_PAIR_CAP per direction are recounted exactly, 16 per wave and
+//     walk of the other image on the matrix pipe (knn2_exact_recount16); a direction with more (overlapping images) is
+//     reported as -1 and the caller runs it on the two-pass kernel.  Counts are therefore the exact counts, bit for bit,
+//     whatever the filter lets through.
 // Column direction (query = item.q image, train = item.t image): as in knn2_count16w_kernel the train norm rides in the
 // MFMA's C input, a lane owns 8 x 16 queries, two max-only streams per column block.  Row direction (query = a row of
 // item.t, candidates = the rows of item.q): the value that ranks along a row is raw - n_q/2; instead of one subtraction
 // per value the element-wise maximum over the wave's 8 column blocks (128 queries = one CLASS) is corrected ONCE by the
-// class's smallest half norm (an upper bound) and tagged with the class, reduced 16 -> 4 lanes (2 DPP steps) and
-// folded into a per-row table in LDS with ds_max_u32; the class's norm spread is taken off again where a LOWER bound is
-// needed.  Rows sorted by norm inside an image (ops.prepare_descriptor_tensor(sort_rows=True); counts do not depend on the
+// class's smallest half norm (an upper bound) and tagged with the class, reduced 16 lanes x 4 registers -> 1 register
+// (a reduce-scatter over the quads, six DPP ops) and folded into a per-row table in LDS with one ds_max_u32; the class's norm spread is taken off again where a LOWER bound is
+// needed.  Rows sorted by norm inside an image (ops.sort_rows_by_norm; counts do not depend on the
 // row order) make that spread small; unsorted input is still exact, only more candidates pass.
 // One workgroup (8 waves, 2 per SIMD) per pair, the query image in 4 passes of 1024; the train image streams through the
 // four LDS-DMA buffers once per pass.
