@@ -1633,8 +1633,8 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
 
         auto run_chunks = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
-            // One step = the 16 matrix instructions of tile X interleaved BY HAND with the fold of the previous tile P (44
-            // vector ops + 4 LDS atomics), three vector ops in the shadow of each matrix instruction: a wave that is left
+            // One step = the 16 matrix instructions of tile X interleaved BY HAND with the fold of the previous tile P (39
+            // vector ops + 1 LDS atomic), two to three vector ops in the shadow of each matrix instruction: a wave that is left
             // to the scheduler issues its fold in blocks, and with two lock-stepped waves per SIMD the matrix pipe then
             // idles while both fold (counters: matrix pipe 51 % busy, 16 % of the cycles co-issued).
             // tile_c: compile-time index of tile P in the chunk, -1 .. 7 (-1 = the previous chunk's last tile, or the dummy tile)
