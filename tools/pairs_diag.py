@@ -11,6 +11,10 @@ do_sort = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 kp, d = (int(sys.argv[3]) if len(sys.argv) > 3 else 4096), 128
 des, scene_of = overlapping_crops_descriptors(seed=1234, n_scenes=max(1, n_img // 64), imgs_per_scene=min(64, n_img), kp=kp, step=kp * 448 // 4096, d=d)
 n_img = des.shape[0]
+if os.environ.get("ISX_DIAG_DATA") == "low":   # power experiment: the same work on bytes of 0/1 (few operand bits toggle in the matrix pipe)
+    des = des & 1
+elif os.environ.get("ISX_DIAG_DATA") == "random":
+    des = np.random.default_rng(1).integers(0, 256, des.shape, dtype=np.uint8)
 src = torch.from_numpy(des.reshape(-1, d)).cuda()
 starts, counts = np.arange(n_img) * kp, np.full((n_img,), kp)
 all_pairs = prs.unordered_pairs(n_img)
