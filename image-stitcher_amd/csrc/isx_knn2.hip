@@ -1322,7 +1322,9 @@ extern "C" int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nr
 // One workgroup (8 waves, 2 per SIMD) per pair, the query image in 4 passes of 1024; the train image streams through the
 // four LDS-DMA buffers once per pass.
 // ------------------------------------------------------------------------------------------------
+#ifndef ISX_PAIR_CAP
 #define ISX_PAIR_CAP 128
+#endif
 #ifndef ISX_PAIR_SPREAD
 #define ISX_PAIR_SPREAD 16384
 #endif /* norm spread of a class (128 query rows) beyond which it takes the per-value correction */
@@ -1462,6 +1464,26 @@ __device__ __noinline__ int knn2_exact_recount16(const int8_t *__restrict__ desc
 // smaller image of a pair is made the train side (results swapped back); a pair beyond those sizes is reported as (-1, -1).
 // KS = 64-byte K steps of a descriptor row: 2 = 128-byte rows (SIFT), 1 = 64-byte rows (AKAZE's 61 bytes, padded): one matrix
 // instruction per tile and column block, the same folds.
+#ifdef ISX_PAIR_STAMP /* timing diagnostic: shader cycles of wave 0 per phase, summed over the workgroups (tools/pairs_diag.py) */
+__device__ unsigned long long isx_pair_stamp[16];
+extern "C" int isx_pair_stamp_read(unsigned long long *out16, int reset) {
+    ISX_HIP_TRY(hipDeviceSynchronize());
+    ISX_HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(isx_pair_stamp), sizeof(isx_pair_stamp)));
+    if (reset) {
+        unsigned long long z[16] = {};
+        ISX_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(isx_pair_stamp), z, sizeof(z)));
+    }
+    return ISX_OK;
+}
+#define ISX_STAMP(k)                                                                               \
+    do {                                                                                           \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                              \
+        if (tid == 0) atomicAdd(&isx_pair_stamp[k], now_ - stamp_t);                               \
+        stamp_t = now_;                                                                            \
+    } while (0)
+#else
+#define ISX_STAMP(k)
+#endif
 template <int WAVES, int NG, int KS>
 __global__ void __launch_bounds__(64 * WAVES)
 knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restrict__ nrm, const int32_t *__restrict__ cin,
@@ -1486,6 +1508,10 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
     isx_knn_item it = items[item_i];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, col = lane & 15;
+#ifdef ISX_PAIR_STAMP
+    unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+    if (tid == 0) atomicAdd(&isx_pair_stamp[15], 1ull);
+#endif
     bool swapped = false;
     if (NG == 2) {
         if (it.nt > it.nq) { // the smaller image is the train side: its rows are what the table holds
@@ -1589,6 +1615,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
 #endif
     load_queries(0);
     stage_first();
+    ISX_STAMP(0); // prologue: item, table clear, first requests
 
     for (int pass = 0; pass < n_pass; pass++) {
         const int q0 = pass * QPB + wave * QPW;
@@ -1777,7 +1804,9 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 step(f0, accA, accB, row_slot_lds + (n_chunks - 1) * (CHUNK * ROWB), std::integral_constant<int, 7>{});
         };
 
+        ISX_STAMP(1); // class set-up (waits for the query norms)
         __syncthreads(); // the first three chunks of this pass have landed (staged before the previous pass's epilogue)
+        ISX_STAMP(2); // wait for the other waves and the first chunks
         // Overlapping images: once the column direction has overflowed its candidate list the pair goes to the two-pass
         // kernel anyway -- leave now (both directions reported as -1) instead of forming the remaining products.  The
         // barrier above has drained this wave's DMA; lst[0] only changes in the column epilogue, before that barrier.
@@ -1801,12 +1830,14 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
             run_chunks(std::integral_constant<int, 1>{});
         else
             run_chunks(std::integral_constant<int, 2>{});
+        ISX_STAMP(3); // the chunk loop
         // every wave is past the last chunk's barrier: the buffers are free.  Start the next pass's first chunks and query
         // rows now, so that they travel while this pass's column results are evaluated.
         if (pass + 1 < n_pass) {
             stage_first();
             if (!(ISX_PAIR_X & 128)) load_queries(pass + 1);
         }
+        ISX_STAMP(8); // (issuing the next pass's requests)
 
         // column direction of this pass: candidates among this wave's 128 queries.  Almost no query is one: every lane
         // first takes the cheap conservative reject (one float product), and only a wave that has a survivor enters the
@@ -1842,8 +1873,10 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
                 }
             }
         }
+        ISX_STAMP(4); // next pass's requests + column epilogue
     }
     __syncthreads();
+    ISX_STAMP(5);
     // row direction: candidates among the train image's rows, from the table
     for (int t = tid; t < nt; t += 64 * WAVES) {
         unsigned E1, E2; // the largest and the second largest of the row's group maxima
@@ -1877,6 +1910,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
         }
     }
     __syncthreads();
+    ISX_STAMP(6); // table scan
     int n_col = lst[0], n_row = lst[1];
     if (ISX_PAIR_T & 32) { // timing diagnostic: exactly 16 recounts per direction, whatever the filter found
         n_col = n_row = 16;
@@ -1903,6 +1937,7 @@ knn2_pair_filter_kernel(const int8_t *__restrict__ desc, const int32_t *__restri
         if (good_row) atomicAdd(&lst[3], good_row);
     }
     __syncthreads();
+    ISX_STAMP(7); // recounts
     if (tid == 0) {
         // ([2e] = the direction whose queries are the ITEM's q image: the column direction unless the roles were swapped)
         count_out[2 * (int64_t)item_i + (swapped ? 1 : 0)] = (ISX_PAIR_T & 16) ? n_col : n_col <= ISX_PAIR_CAP ? lst[2] : -1;

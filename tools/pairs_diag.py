@@ -31,11 +31,19 @@ for rep in range(3):
     _lib.check(L.isx_knn2_l2_count_pairs(_ptr(P.desc), _ptr(P.nrm), _ptr(P.cin), 128, _ptr(items_dev), m, kp, 0.65, _ptr(c), 0, _stream()))
     ev[1].record(); torch.cuda.synchronize()
     print(f"{os.environ.get('ISX_LIB_PATH', 'product')}: pairs={m} {ev[0].elapsed_time(ev[1]):.2f} ms", flush=True)
+if hasattr(L, "isx_pair_stamp_read"):   # -DISX_PAIR_STAMP build: wave 0's shader cycles per phase, mean per pair
+    import ctypes
+    buf = (ctypes.c_ulonglong * 16)()
+    _lib.check(L.isx_pair_stamp_read(buf, 1))
+    v = np.array(list(buf), float); n = max(v[15], 1)
+    names = ["prologue", "class set-up", "pass-start wait", "chunk loop", "requests + column epilogue", "after the last pass (barrier)", "table scan", "recounts", "issuing the requests"]
+    tot = v[:9].sum()
+    print("stamps over", int(n), "workgroups: " + ", ".join(f"{nm} {v[k]/n:.0f} ({100*v[k]/tot:.1f} %)" for k, nm in enumerate(names)) + f" | total {tot/n:.0f} cycles per pair")
 h = c[inv_dev].cpu().numpy() if inv_np is not None else c.cpu().numpy()
 cross = scene_of[all_pairs[:, 0]] != scene_of[all_pairs[:, 1]]
 print("values: cross-scene mean %.2f max %d | same-scene: <0: %d, mean of the rest %.2f, histogram of all >=0: %s" % (
     h[cross].mean(), h[cross].max(), (h[~cross] < 0).sum(), h[~cross][h[~cross] >= 0].mean() if (h[~cross] >= 0).any() else -1,
-    np.histogram(h[h >= 0], bins=[0, 1, 2, 4, 8, 16, 32, 64, 129, 100000])[0].tolist()))
+    np.histogram(h[h >= 0], bins=[0, 1, 2, 4, 8, 16, 32, 64, 129, 257, 513, 1025, 2049, 3073, 100000])[0].tolist()))
 bad = np.argwhere((h > 16) & cross[:, None])
 print("cross-scene entries > 16:", len(bad), "by direction", np.bincount(bad[:, 1], minlength=2).tolist())
 for p, dd in bad[:12]:
