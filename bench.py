@@ -485,7 +485,12 @@ def main():
                                  "two HIP events: knn2_pair_filter_kernel over every pair (one distance matrix per pair) and "
                                  f"knn2_count16w_kernel over the {stage.get('overflow_directions')} of {2 * len(my_pairs)} directions the filter "
                                  "reports as overflowing (overlapping images), incl. the list compaction between them",
-                         "overflow_directions": None if two_pass else stage.get("overflow_directions")},
+                         "overflow_directions": None if two_pass else stage.get("overflow_directions"),
+                         # context, not a second roofline: what this chip sustains on the kernel's bare instruction mix
+                         "sustained_reference": {"value": 3459.0, "unit": "TFLOP/s", "measured": "2026-11-11, not in this run",
+                                                 "source": "tools/mfma_rate.hip ('s'): 16 v_mfma_i32_16x16x64_i8 + 40 v_max3_u32 per step, "
+                                                           "2 waves per SIMD, SIFT-like operand bytes, no LDS or memory traffic; the clock "
+                                                           "gives way under this mix (profiles/r03_knn2_count_pmc.md)"}},
         }
         line["step_breakdown"] = breakdown
         if world == 1 and not args.no_cpu_baseline:
