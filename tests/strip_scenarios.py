@@ -13,6 +13,21 @@ def _rot(deg, tx, ty):
     return [[c, -s, tx], [s, c, ty]]
 
 
+def uhd_scenarios():
+    """BASELINE configs[4]'s frame size: three 3840x2160 frames marching down (1760 new rows each), so the mosaic ends 5680 rows
+    tall and every frame's ROI crosses the boundary between the two strips.  Same tuple layout as scenarios()."""
+    from image_stitcher_amd.synthetic import procedural_world
+    world = procedural_world(seed=7, h=1320, w=2300).repeat(2, axis=0).repeat(2, axis=1)  # (2640, 4600): a quarter of the generation time
+    ih, iw = 2160, 3840
+    frames = [np.ascontiguousarray(world[y:y + ih, x:x + iw]) for y, x in ((0, 0), (230, 310), (480, 700))]
+    Ms, rh = [], ih
+    for k, (deg, tx) in enumerate(((0.3, 13.7), (-0.25, -21.3))):
+        ty = (ih + rh - 400) - (rh + ih) // 2 + 0.4
+        Ms.append(_rot(deg, tx, ty))
+        rh += ih - 400
+    return [("uhd_down_b1", frames, Ms, 0, 1, 0.4)]
+
+
 def scenarios():
     """[(name, frames, Ms, type, blender, contrib)] -- every M is given in the reference's padded-canvas coordinates
     (frame at ((rw+iw)//2, (rh+ih)//2), mosaic at (iw, ih)); the placements only have to overlap roughly."""

@@ -15,7 +15,7 @@ for p in (HERE, ROOT, os.path.join(ROOT, "image-stitcher_amd")):
         sys.path.insert(0, p)
 
 
-def main(outdir):
+def main(outdir, which="small"):
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     torch.cuda.set_device(0)
@@ -23,10 +23,10 @@ def main(outdir):
     from image_stitcher_amd import ArbitraryStitcher, Stitcher, TransformDetails
     from image_stitcher_amd.detect import NumpyOrbLite
     from image_stitcher_amd.strips import StripMosaic
-    from strip_scenarios import collection_images, scenarios
+    from strip_scenarios import collection_images, scenarios, uhd_scenarios
     pts = np.zeros((5, 1, 2), np.float32)
     results = {}
-    for name, frames, Ms, type_, blender, contrib in scenarios():
+    for name, frames, Ms, type_, blender, contrib in (uhd_scenarios() if which == "uhd" else scenarios()):
         st = Stitcher(log_level=3, type=type_, blender=blender, ref_image_contrib=contrib, consecutive_range=1,
                       detector=object(), device=dev)
         m = StripMosaic.from_image(frames[0], dist.group.WORLD, dev)
@@ -53,6 +53,12 @@ def main(outdir):
             dist.all_gather_object(owns, own)
             per_frame.append((full, corners, owns))
         results[name] = (per_frame, dict(st.frame_stats))
+    if which == "uhd":
+        if rank == 0:
+            np.save(os.path.join(outdir, "results_uhd.npy"), np.array([results, None], dtype=object), allow_pickle=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # the greedy merge with a real detector: the detector regions are assembled from both strips
     images = collection_images()
     ar = ArbitraryStitcher(images=list(images), with_tqdm=False, log_level=3, algorithm=1, detector=NumpyOrbLite(nfeatures=500),
@@ -67,4 +73,4 @@ def main(outdir):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:3])

@@ -17,24 +17,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_hold_strips_that_concatenate_to_the_single_gpu_mosaic(cuda, orc, tmp_path):
-    from PIL import Image
-    from image_stitcher_amd import ArbitraryStitcher
-    from image_stitcher_amd.detect import NumpyOrbLite
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from strip_scenarios import collection_images, scenarios
+def _run_worker(tmp_path, *extra):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    os.makedirs(tmp_path / "strips")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "strip_worker.py"), str(tmp_path)]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "strip_worker.py"), str(tmp_path), *extra]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, (r.stdout[-1500:] + r.stderr[-3000:])
-    results, cols = np.load(tmp_path / "results.npy", allow_pickle=True)  # written by the worker of this test
+
+
+def _check_against_the_oracle(scenario_list, results):
+    """every frame of every scenario: the gathered strips equal the oracle's single canvas, the corners too, and the ranks'
+    rows tile the mosaic.  Returns how many frames ended on a mosaic that both ranks hold rows of."""
     pts = np.zeros((5, 1, 2), np.float32)
     straddled = 0
-    for name, frames, Ms, type_, blender, contrib in scenarios():
+    for name, frames, Ms, type_, blender, contrib in scenario_list:
         per_frame, stats = results[name]
         cfg = Cfg(type=type_, blender=blender, ref_image_contrib=contrib, consecutive_range=1)
         ref, corners = frames[0], None
@@ -50,6 +48,34 @@ def test_two_ranks_hold_strips_that_concatenate_to_the_single_gpu_mosaic(cuda, o
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             straddled += len(spans) == 2
             ref, corners = o[0], o[1]
+    return straddled
+
+
+def test_two_ranks_stitch_uhd_frames_across_the_strip_boundary(cuda, orc, tmp_path):
+    """BASELINE configs[4]'s frame size on the strip partition: 3840 x 2160 frames, the mosaic growing to 5680 rows."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from strip_scenarios import uhd_scenarios
+    _run_worker(tmp_path, "uhd")
+    results, _ = np.load(tmp_path / "results_uhd.npy", allow_pickle=True)  # written by the worker of this test
+    sc = uhd_scenarios()
+    assert _check_against_the_oracle(sc, results) == 2
+    per_frame, stats = results["uhd_down_b1"]
+    assert per_frame[-1][0].shape[0] > 5500 and per_frame[-1][0].shape[1] >= 3840
+    assert stats["rows_slow"] == 0 and stats["rescans"] == 0
+
+
+def test_two_ranks_hold_strips_that_concatenate_to_the_single_gpu_mosaic(cuda, orc, tmp_path):
+    from PIL import Image
+    from image_stitcher_amd import ArbitraryStitcher
+    from image_stitcher_amd.detect import NumpyOrbLite
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from strip_scenarios import collection_images, scenarios
+    os.makedirs(tmp_path / "strips")
+    _run_worker(tmp_path)
+    results, cols = np.load(tmp_path / "results.npy", allow_pickle=True)  # written by the worker of this test
+    straddled = _check_against_the_oracle(scenarios(), results)
+    for name, frames, Ms, type_, blender, contrib in scenarios():
+        per_frame, stats = results[name]
         if name == "rows_slow":
             assert stats["rows_slow"] == 1
         if name == "alpha_wrap_b0":
