@@ -32,6 +32,8 @@ SIGNATURES = {
                                         c_int, c_void_p]),
     "isx_knn2_l2_count_pairs": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_double, c_void_p,
                                         c_int, c_void_p]),
+    "isx_sort_rows_by_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "isx_knn2_l2_wide_items": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
     "isx_knn2_hamming_items": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p,

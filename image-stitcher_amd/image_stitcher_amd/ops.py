@@ -130,7 +130,18 @@ def sort_rows_by_norm(P):
     if len(counts) == 0 or not np.array_equal(starts, np.concatenate([[0], np.cumsum(counts)[:-1]])) or int(counts.sum()) != rows:
         return P
     dev = P.device
-    with torch.cuda.device(dev):
+    max_count = int(counts.max())
+    if max_count <= SORT_MAX_ROWS:
+        # one workgroup per image: keys in LDS, bitonic sort, the rows moved by the same workgroup (csrc/isx_rowsort.hip)
+        uniform = int(counts[0]) if len(set(counts.tolist())) == 1 else 0
+        with torch.cuda.device(dev):
+            st_dev = None if uniform else torch.from_numpy(np.concatenate([starts, [rows]]).astype(np.int32)).to(dev)
+            src = [t.contiguous() for t in (P.desc, P.cbase, P.nrm, P.cin)]
+            out = [torch.empty_like(t) for t in src]
+            check(_lib.lib().isx_sort_rows_by_norm(_ptr(src[0]), _ptr(src[1]), _ptr(src[2]), _ptr(src[3]), P.d_pad,
+                                                   _ptr(st_dev), len(counts), uniform, max_count, *[_ptr(t) for t in out], _stream()))
+        return PreparedDescriptors(out[0], out[1], out[2], out[3], P.starts, P.counts, P.d, P.d_pad, P.max_norm2, P.wide)
+    with torch.cuda.device(dev):  # an image beyond ISX_SORT_MAX_ROWS rows: the same order (up to ties) with torch's sort
         if len(set(counts.tolist())) == 1:
             img = torch.arange(rows, device=dev, dtype=torch.int64) // int(counts[0])
         else:
@@ -156,6 +167,7 @@ def sort_rows_by_norm(P):
 FRAME_MAX_Q = 32768    # include/isx.h ISX_FRAME_MAX_Q: largest side of the rectangle isx_frame_blend warps into
 PAIR_MAX_ROWS = 4096   # isx_knn2_l2_count_pairs: rows per image for its four-group table (the per-row table lives in LDS)
 PAIR_BIG_TRAIN, PAIR_BIG_QUERY = 8192, 16384  # beyond: two groups per row -- rows of the smaller / the larger image of a pair
+SORT_MAX_ROWS = 16384  # include/isx.h ISX_SORT_MAX_ROWS: rows per image isx_sort_rows_by_norm sorts in LDS
 PAIR_MIN_ITEMS = 512   # below this many pairs the one-workgroup-per-pair kernel does not beat the directed kernel (tools/pairs_min_items.py)
 
 

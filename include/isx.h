@@ -51,7 +51,7 @@ enum isx_blender { ISX_BLEND_ALPHA = 0, ISX_BLEND_GRADIENT = 1 };          /* st
  * before anything else (image_stitcher_amd._lib does).  History: 1 = round 1; 2 = round 2 (bbox_out_dev of isx_bbox_nonzero /
  * isx_warp / isx_warp_arith / isx_warp_alpha_blend grew from int32[5] to int32[ISX_BBOX_INTS] under unchanged names: a
  * round-1 caller passing 5 ints would be overwritten -- that is what this number is for); 3 = round 3 (additions only:
- * isx_knn2_l2_count_pairs, isx_warp16, isx_alpha_blend16). */
+ * isx_knn2_l2_count_pairs, isx_sort_rows_by_norm, isx_warp16, isx_alpha_blend16). */
 #define ISX_ABI_VERSION 3
 int isx_version(void);
 const char *isx_last_error(void);
@@ -136,6 +136,20 @@ int isx_knn2_l2_count_items(const int8_t *desc_dev, const int32_t *nrm_dev, cons
 int isx_knn2_l2_count_pairs(const int8_t *desc_dev, const int32_t *nrm_dev, const int32_t *cin_dev, int d_pad,
                             const isx_knn_item *items_dev, int n_items, int max_rows, double ratio,
                             int32_t *count_out_dev, int flags, void *stream);
+
+/* The row order isx_knn2_l2_count_pairs likes: the prepared rows of every image (isx_desc_prep's four outputs) sorted by
+ * nrm, ties by row, and rotated by 64 where an image has more than 256 rows (its 64 smallest norms follow its 64 largest:
+ * one class of widely spread norms per image instead of two).  No counterpart in the reference: stitcher.py:292-296 uses only
+ * len(good_matches) of a pair, which does not depend on the row order of either image -- use the sorted set for the count
+ * entry points only (isx_knn2_l2_items reports row indices).
+ *   images back to back: image i = rows [starts_dev[i], starts_dev[i + 1]) (n_images + 1 int32 on the device), or
+ *   starts_dev = NULL and every image has uniform_count rows; max_count = the largest image (<= ISX_SORT_MAX_ROWS, else
+ *   ISX_E_UNSUPPORTED).  Out of place: the four outputs are as large as the inputs and none may alias its input. */
+#define ISX_SORT_MAX_ROWS 16384
+int isx_sort_rows_by_norm(const int8_t *desc_in_dev, const uint32_t *cbase_in_dev, const int32_t *nrm_in_dev,
+                          const int32_t *cin_in_dev, int d_pad, const int32_t *starts_dev, int n_images, int uniform_count,
+                          int max_count, int8_t *desc_out_dev, uint32_t *cbase_out_dev, int32_t *nrm_out_dev,
+                          int32_t *cin_out_dev, void *stream);
 
 /* The same matcher without a norm limit: exact L2 kNN-2 + ratio for byte descriptors whose squared distances can
  * leave the range where sqrtf is injective (2*max||v||^2 >= ISX_L2_EXACT_LIMIT: saturated AKAZE / ORB rows).  Ranks on

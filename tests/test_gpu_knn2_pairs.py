@@ -101,6 +101,32 @@ def test_sorted_rows_leave_counts_unchanged_and_shrink_the_candidate_lists(cuda)
     assert np.array_equal(ops.knn2_l2_items(P, it, 0.7).cpu().numpy(), ops.knn2_l2_items(S, it, 0.7).cpu().numpy())
 
 
+@pytest.mark.parametrize("d", [128, 61, 32])
+def test_sort_rows_by_norm_is_the_stated_permutation(cuda, d):
+    """isx_sort_rows_by_norm against numpy: per image the rows in (norm, row) order, rotated by 64 where the image has more than
+    256 rows -- all four per-row arrays, ragged sets (empty, 1, 255 / 256 / 257 rows, beyond 4096 and at the 16384 limit) and
+    the equal-count form; an image beyond the limit takes the torch route and gives the same norms."""
+    import torch
+    from image_stitcher_amd import ops
+    rng = np.random.default_rng(77 + d)
+    for sizes in ([0, 1, 255, 256, 257, 1000, 0, 4096, 5000, 64], [16384, 3, 700], [512] * 7, [16385, 300]):
+        des = [rng.integers(0, 40, (n, d)).astype(np.uint8) for n in sizes]  # (small values: many equal norms)
+        P = ops.prepare_descriptors(des)
+        S = ops.sort_rows_by_norm(P)
+        nrm = P.nrm.cpu().numpy()
+        exact = max(sizes) <= ops.SORT_MAX_ROWS
+        for s, c in zip(P.starts, P.counts):
+            s, c = int(s), int(c)
+            order = np.lexsort((np.arange(c), nrm[s:s + c]))
+            if c > 256:
+                order = np.roll(order, -64)
+            if exact:
+                for a, b in ((P.desc, S.desc), (P.cbase, S.cbase), (P.nrm, S.nrm), (P.cin, S.cin)):
+                    assert torch.equal(a[s:s + c][torch.from_numpy(order).to(a.device)], b[s:s + c]), (sizes, s, c)
+            else:
+                assert np.array_equal(nrm[s:s + c][order], S.nrm[s:s + c].cpu().numpy())
+
+
 def test_pairs_kernel_refuses_what_it_cannot_run(cuda):
     from image_stitcher_amd import ops
     from image_stitcher_amd._lib import IsxError
