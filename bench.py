@@ -8,7 +8,8 @@ Workload (BASELINE.json configs[2], the configuration the metric "image pairs ma
 is quoted on; it fits one GPU): ArbitraryStitcher.get_collections over 512 shuffled crops x 4096
 SIFT-like keypoints (integer-valued 128-d descriptors, 8 planted scenes of 64 overlapping images,
 SURVEY.md section 8d).  One STEP = one full all-pairs pass: descriptor preparation (+ rows sorted by norm) of the
-rank's own images -> [all_gather of the prepared rows over RCCL when N>1] -> fused kNN-2 + Lowe-ratio
+rank's own images -> [all_gather of the prepared rows over RCCL when N>1, started asynchronously: the pairs among the rank's
+own images are counted while it travels] -> fused kNN-2 + Lowe-ratio
 counts of both directions of this rank's share of the 130,816 unordered pairs (one launch over all pairs,
 one over the overlapping ones) -> gather of the int32 good-match counts -> host union-find on rank 0 (deferred by one step:
 it runs while the next step's kernel is on the GPU; the last one before the closing fence).  Inputs (the raw uint8 descriptor shard) are resident in HBM
@@ -336,10 +337,26 @@ def main():
     # (max-only filter + exact recount of the candidates); the directions it reports as overflowing (overlapping images)
     # run on the two-pass kernel isx_knn2_l2_count_items inside the same step.  ISX_BENCH_TWO_PASS=1: round 2's path.
     two_pass = os.environ.get("ISX_BENCH_TWO_PASS") == "1"
-    plan = ops.plan_items(prs.directed_items(my_pairs, starts, counts) if two_pass else prs.pair_items(my_pairs, starts, counts), dev)
+    # N > 1: the all_gather of the prepared rows is started asynchronously and hidden behind the pairs a rank can form from its
+    # OWN images (C(n / N, 2) of them, the same number on every rank); the pairs that span two shards are dealt round-robin and
+    # run when the gather has landed.  ISX_BENCH_OVERLAP=0: gather first, then one launch over pairs p % N (the earlier form).
+    overlap = world > 1 and not two_pass and os.environ.get("ISX_BENCH_OVERLAP", "1") == "1"
+    result_pairs = all_pairs  # the pair each row of rank 0's gathered counts belongs to
+    if overlap:
+        loc_lists, x_lists = prs.overlap_shards(n, world)
+        my_loc, my_x = loc_lists[rank], x_lists[rank]
+        my_pairs = np.concatenate([my_loc, my_x])
+        plan_loc = ops.plan_items(prs.pair_items(my_loc - rank * per, starts[:per], counts[:per]), dev) if len(my_loc) else None
+        plan = ops.plan_items(prs.pair_items(my_x, starts, counts), dev)
+        list_lens = [len(a) + len(b) for a, b in zip(loc_lists, x_lists)]
+        result_pairs = np.concatenate([np.concatenate([a, b]) for a, b in zip(loc_lists, x_lists)])
+    else:
+        plan = ops.plan_items(prs.directed_items(my_pairs, starts, counts) if two_pass else prs.pair_items(my_pairs, starts, counts), dev)
     stage = {}
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(5)]  # step start | after all_gather | after kernel | after gather | [4] after local prep
+    ev_loc = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    # step start | all_gather landed | after the kernels | after gather | [4] after local prep | [5] after the local pairs (overlap)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
     kernel_ms, parts = [], []
     result = {}
 
@@ -355,7 +372,7 @@ def main():
             pending[0] = None
             done.synchronize()
             h = hb.numpy()
-            comps, _ = prs.components_from_counts(n, all_pairs, h[:, 0], h[:, 1], min_match)
+            comps, _ = prs.components_from_counts(n, result_pairs, h[:, 0], h[:, 1], min_match)
             result["comps"], result["counts"] = comps, h.copy()
 
     def step(record):
@@ -369,16 +386,36 @@ def main():
             Pl = ops.sort_rows_by_norm(Pl)
         if record:
             marks[4].record()
-        P = prs.all_gather_prepared(Pl, starts, counts) if world > 1 else Pl
-        if record:
-            marks[1].record()
-        if two_pass:
-            c = ops.knn2_l2_items(P, None, ratio, plan=plan, events=ev if record else None)
+        if overlap:
+            landed = prs.all_gather_prepared(Pl, starts, counts, async_op=True)  # travels on the backend's stream from here on
+            st_loc = {}
+            c_loc = (ops.knn2_l2_pairs(Pl, None, ratio, plan=plan_loc, events=ev_loc if record else None, stats=st_loc,
+                                       while_running=finish_pending) if plan_loc is not None
+                     else torch.zeros((0, 2), dtype=torch.int32, device=dev))
+            if record:
+                marks[5].record()
+            P = landed()  # the current stream waits for the gather (the host does not)
+            if record:
+                marks[1].record()
+            c_x = ops.knn2_l2_pairs(P, None, ratio, plan=plan, events=ev if record else None, stats=stage)
+            stage["overflow_directions"] = stage.get("overflow_directions", 0) + st_loc.get("overflow_directions", 0)
+            c = torch.cat([c_loc.view(-1, 2), c_x.view(-1, 2)])
         else:
-            c = ops.knn2_l2_pairs(P, None, ratio, plan=plan, events=ev if record else None, stats=stage, while_running=finish_pending)
+            P = prs.all_gather_prepared(Pl, starts, counts) if world > 1 else Pl
+            if record:
+                marks[1].record()
+            if two_pass:
+                c = ops.knn2_l2_items(P, None, ratio, plan=plan, events=ev if record else None)
+            else:
+                c = ops.knn2_l2_pairs(P, None, ratio, plan=plan, events=ev if record else None, stats=stage, while_running=finish_pending)
         if record:
             marks[2].record()
-        allc = prs.gather_counts(c.view(-1, 2), len(all_pairs), rank, world)
+        if overlap:
+            allc = prs.gather_rank_lists(c, max(list_lens), rank, world)  # rank 0: (world, longest list, 2)
+            if rank == 0:
+                allc = torch.cat([allc[r, :list_lens[r]] for r in range(world)])  # rows in result_pairs' order
+        else:
+            allc = prs.gather_counts(c.view(-1, 2), len(all_pairs), rank, world)
         if record:
             marks[3].record()
             torch.cuda.synchronize()  # (instrumented steps only: the host figure below must not include the wait for the GPU)
@@ -396,12 +433,17 @@ def main():
         if record:
             torch.cuda.synchronize()
             host_ms = (time.perf_counter() - t_host) * 1e3
-            kernel_ms.append(ev[0].elapsed_time(ev[1]))
-            # per-phase GPU time of this rank's step: all_gather of the prepared rows | desc_prep + sort of the rank's own
-            # images + count kernels | gather; host = counts
-            # read-back + union-find (rank 0)
-            parts.append((marks[4].elapsed_time(marks[1]), marks[0].elapsed_time(marks[4]) + marks[1].elapsed_time(marks[2]),
-                          marks[2].elapsed_time(marks[3]), host_ms))
+            # per-phase GPU time of this rank's step: all_gather of the prepared rows (overlap: only what of it is still
+            # outstanding when the rank's local pairs are done) | desc_prep + sort of the rank's own images + count kernels |
+            # gather; host = counts read-back + union-find (rank 0)
+            if overlap:
+                kernel_ms.append(ev[0].elapsed_time(ev[1]) + (ev_loc[0].elapsed_time(ev_loc[1]) if plan_loc is not None else 0.0))
+                parts.append((marks[5].elapsed_time(marks[1]), marks[0].elapsed_time(marks[5]) + marks[1].elapsed_time(marks[2]),
+                              marks[2].elapsed_time(marks[3]), host_ms))
+            else:
+                kernel_ms.append(ev[0].elapsed_time(ev[1]))
+                parts.append((marks[4].elapsed_time(marks[1]), marks[0].elapsed_time(marks[4]) + marks[1].elapsed_time(marks[2]),
+                              marks[2].elapsed_time(marks[3]), host_ms))
 
     def fence():
         finish_pending()
@@ -473,7 +515,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"ArbitraryStitcher.get_collections all-pairs: {n} images x {kp} SIFT-like kp x {d}-d "
                                    f"({pairs_per_step} unordered pairs, both directions, ratio {ratio}, min_match {min_match})",
-                       "pairs_per_step": pairs_per_step, "parallelism": f"pair-sharded x{world}",
+                       "pairs_per_step": pairs_per_step,
+                       "parallelism": f"pair-sharded x{world}" + (" (own-shard pairs first, behind the all_gather)" if overlap else ""),
                        "components_correct": bool(ok)},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": INT8_DENSE_PEAK_TOPS, "unit": "TFLOP/s",
                          "frac": achieved / INT8_DENSE_PEAK_TOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -492,6 +535,8 @@ def main():
                                                            "2 waves per SIMD, SIFT-like operand bytes, no LDS or memory traffic; the clock "
                                                            "gives way under this mix (profiles/r03_knn2_count_pmc.md)"}},
         }
+        if overlap:
+            line["roofline"]["note"] += ".  N > 1: kernel_ms is the sum of the own-shard call and the cross-shard call"
         line["step_breakdown"] = breakdown
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(des, all_pairs, ratio, args.cpu_seconds, gpu_counts=result["counts"])

@@ -81,6 +81,27 @@ def test_pair_sharding_covers_every_pair_once():
     assert it.shape == (6, 4) and (it[0] == [0, 10, 10, 10]).all() and (it[1] == [10, 10, 0, 10]).all()
 
 
+def test_overlap_shards_split_the_pair_list_into_own_and_cross_pairs():
+    """pairs.overlap_shards (bench.py at N > 1): every unordered pair exactly once; a rank's own pairs lie inside its image
+    shard and number C(n / N, 2); the cross pairs are spread evenly."""
+    from image_stitcher_amd import pairs as prs
+    for n, world in ((16, 2), (24, 4), (64, 8), (6, 3), (8, 8)):
+        loc, cross = prs.overlap_shards(n, world)
+        per = n // world
+        assert len(loc) == len(cross) == world
+        seen = set()
+        for r in range(world):
+            assert len(loc[r]) == per * (per - 1) // 2
+            assert all(r * per <= a < b < (r + 1) * per for a, b in loc[r])
+            assert all(a < b and a // per != b // per for a, b in cross[r])
+            seen |= {(int(a), int(b)) for a, b in loc[r]} | {(int(a), int(b)) for a, b in cross[r]}
+        assert len(seen) == n * (n - 1) // 2 == sum(len(a) + len(b) for a, b in zip(loc, cross))
+        sizes = [len(c) for c in cross]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        prs.overlap_shards(10, 4)
+
+
 def _prepared_worker(rank, world, port, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -99,6 +120,21 @@ def _prepared_worker(rank, world, port, out_path):
                                      np.arange(per) * kp, np.full(per, kp), 128, d_pad, 12345, False)
         starts, counts = np.arange(n) * kp, np.full(n, kp)
         P = prs.all_gather_prepared(Pl, starts, counts)
+        # the asynchronous form (bench.py at N > 1: the gather hides behind the rank's own-shard pairs) hands over the same set
+        landed = prs.all_gather_prepared(Pl, starts, counts, async_op=True)
+        _own = (Pl.desc.to(torch.int32).sum(), Pl.nrm.sum())   # (work queued while the collective travels)
+        Pa = landed()
+        for a, b in ((P.desc, Pa.desc), (P.cbase, Pa.cbase), (P.nrm, Pa.nrm), (P.cin, Pa.cin)):
+            assert torch.equal(a, b)
+        # ... and the per-rank result lists come back to rank 0 row by row
+        mine = torch.full((2 + rank, 2), rank + 1, dtype=torch.int32)
+        got = prs.gather_rank_lists(mine, 2 + world, rank, world)
+        if rank == 0:
+            assert got.shape == (world, 2 + world, 2)
+            for r in range(world):
+                assert int(got[r, :2 + r].min()) == r + 1 == int(got[r, :2 + r].max()) and int(got[r, 2 + r:].abs().max()) == 0
+        else:
+            assert got is None
         assert P.desc.shape == (n * kp, d_pad) and P.desc.dtype == torch.int8 and P.desc.is_contiguous()
         assert P.nrm.shape == (n * kp,) and P.nrm.dtype == torch.int32
         np.savez(out_path + f".{rank}.npz", desc=Pl.desc.numpy(), cbase=Pl.cbase.numpy(), nrm=Pl.nrm.numpy(), cin=Pl.cin.numpy(),

@@ -14,11 +14,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_share_one_gpu(cuda):
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_two_ranks_share_one_gpu(cuda, overlap):
+    """overlap 1 (bench.py's default at N > 1): the gather of the prepared rows travels behind the ranks' own-shard pairs;
+    0: gather first, then one launch over pairs p % N."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, ISX_BENCH_BACKEND="gloo")
+    env = dict(os.environ, ISX_BENCH_BACKEND="gloo", ISX_BENCH_OVERLAP=overlap)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--scenes", "2", "--imgs-per-scene", "8", "--kp", "1024"]
@@ -30,6 +33,7 @@ def test_two_ranks_share_one_gpu(cuda):
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "strong"
     assert d["metric"] == "image pairs matched/sec (SIFT 4k kp)" and d["unit"] == "image pairs/s" and d["higher_is_better"] is True
     assert d["config"]["components_correct"] is True and d["config"]["pairs_per_step"] == 120
+    assert ("own-shard pairs first" in d["config"]["parallelism"]) == (overlap == "1")
     assert d["value"] > 0 and abs(d["value"] - 120 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d and "stitch" not in d           # rank-0-at-N=1 extras only
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1

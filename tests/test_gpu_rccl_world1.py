@@ -37,6 +37,19 @@ def test_rccl_collectives_world_of_one(cuda):
         assert P.desc.shape == Pl.desc.shape and P.desc.dtype == torch.int8 and P.desc.data_ptr() % 16 == 0
         for a, b in ((P.desc, Pl.desc), (P.cbase, Pl.cbase), (P.nrm, Pl.nrm), (P.cin, Pl.cin)):
             assert a.dtype == b.dtype and torch.equal(a, b)
+        # bench.py at N > 1: the same collective started asynchronously, the rank's own-shard pairs counted while it
+        # travels on RCCL's stream, then the current stream (not the host) waits for it
+        from image_stitcher_amd import pairs as prs2
+        own = prs2.pair_items(prs2.unordered_pairs(4), st, ct)
+        want = ops.knn2_l2_pairs(Pl, own, 0.65)
+        landed = prs.all_gather_prepared(Pl, st, ct, always=True, async_op=True)
+        got_own = ops.knn2_l2_pairs(Pl, own, 0.65)
+        Pa = landed()
+        got_all = ops.knn2_l2_pairs(Pa, own, 0.65)
+        torch.cuda.synchronize()
+        for a, b in ((Pa.desc, Pl.desc), (Pa.cbase, Pl.cbase), (Pa.nrm, Pl.nrm), (Pa.cin, Pl.cin)):
+            assert a.dtype == b.dtype and torch.equal(a, b)
+        assert torch.equal(got_own, want) and torch.equal(got_all, want)
         counts = torch.from_numpy(rng.integers(0, 4096, (37, 2)).astype(np.int32)).to(dev)
         allc = prs.gather_counts(counts, 37, 0, 1, always=True)
         assert allc.shape == (37, 2) and torch.equal(allc, counts)
